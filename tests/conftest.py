@@ -1,0 +1,41 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def golden(name):
+    path = os.path.join(GOLDEN, name + ".npz")
+    if not os.path.exists(path):
+        pytest.skip("golden fixture %s not present" % name)
+    with np.load(path, allow_pickle=False) as z:
+        return {k: z[k] for k in z.files}
+
+
+ICP_CASES = ["c1_30pts", "cow_tr1", "syn256", "syn1k", "syn3k_4k", "lattice", "syn20k", "horse_tr1", "bun045_000"]
+SMALL_ICP_CASES = ["c1_30pts", "cow_tr1", "syn256", "syn1k", "syn3k_4k", "lattice"]
+
+
+def relerr(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    scale = max(np.abs(b).max(), 1e-300)
+    return float(np.abs(a - b).max() / scale)
+
+
+def relerr_t(t, t_ref, Qc, Pc):
+    """t = Qc - Pc.R^T cancels to ~0 once the clouds are aligned, so its error is measured against the
+    size of the operands it is computed from (max of |t|, |Qc|, |Pc|), not against |t| alone."""
+    scale = max(np.abs(t_ref).max(), np.abs(Qc).max(), np.abs(Pc).max(), 1e-300)
+    return float(np.abs(np.asarray(t) - np.asarray(t_ref)).max() / scale)

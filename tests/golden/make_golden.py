@@ -1,0 +1,233 @@
+#!/usr/bin/env python3
+"""Generate the committed golden vectors under tests/golden/ from the UNMODIFIED reference.
+
+Runs oracle/_ref/ref_trace (oracle/ref_trace.cpp linked against the reference's own CPU sources, built by
+oracle/Makefile where they lie under /root/reference) on reference data files and on synthetic /
+adversarial clouds, and packs inputs + per-iteration outputs into small .npz files.  Only data is stored
+(inputs and expected outputs); no reference source travels.  Re-run only in the build container:
+
+    make -C oracle ref && python tests/golden/make_golden.py [case ...]
+"""
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+from icp_amd import synth  # noqa: E402
+
+REF = "/root/reference/data"
+TRACE = os.path.join(ROOT, "oracle", "_ref", "ref_trace")
+
+
+def load_csv(path):
+    rows = []
+    with open(path) as f:
+        for k, line in enumerate(f):
+            tok = line.strip().split(",")
+            try:
+                rows.append([float(x) for x in tok])
+            except ValueError:
+                if k != 0:
+                    raise
+    return np.array(rows, dtype=np.float64)
+
+
+def write_csv(path, A):
+    with open(path, "w") as f:
+        f.write("Points_0,Points_1,Points_2\n")
+        for r in A:
+            f.write("%.17g,%.17g,%.17g\n" % tuple(r))
+
+
+def read_trace(path):
+    raw = open(path, "rb").read()
+    assert raw[:8] == b"ICPTRACE"
+    n, m, iters, flags = np.frombuffer(raw, dtype=np.uint64, count=4, offset=8).astype(int)
+    off = 40
+    def take(count, dtype=np.float64):
+        nonlocal off
+        a = np.frombuffer(raw, dtype=dtype, count=count, offset=off)
+        off += a.nbytes
+        return a.copy()
+    out = {"Qc": take(3)}
+    keys = ("P_in", "Pc", "idx", "cov", "S", "U", "VT", "R", "t")
+    acc = {k: [] for k in keys}
+    for _ in range(iters):
+        if flags & 1:
+            acc["P_in"].append(take(n * 3).reshape(n, 3))
+        acc["Pc"].append(take(3))
+        acc["idx"].append(take(n, np.int32))
+        acc["cov"].append(take(9).reshape(3, 3))
+        acc["S"].append(take(3))
+        acc["U"].append(take(9).reshape(3, 3))
+        acc["VT"].append(take(9).reshape(3, 3))
+        acc["R"].append(take(9).reshape(3, 3))
+        acc["t"].append(take(3))
+    out["P_out"] = take(n * 3).reshape(n, 3)
+    assert off == len(raw)
+    for k in keys:
+        if acc[k]:
+            out[k] = np.stack(acc[k])
+    return out
+
+
+def run_icp_case(name, P, Q, iters, keep_p=None, pfile=None, qfile=None):
+    with tempfile.TemporaryDirectory() as td:
+        if pfile is None:
+            pfile, qfile = os.path.join(td, "P.csv"), os.path.join(td, "Q.csv")
+            write_csv(pfile, P)
+            write_csv(qfile, Q)
+        out = os.path.join(td, "trace.bin")
+        subprocess.check_call([TRACE, pfile, qfile, str(iters), out, "1"])
+        tr = read_trace(out)
+    # the reference loop starts from the parsed input: pin our parse / csv round-trip against it
+    assert np.array_equal(tr["P_in"][0], P), name
+    keep = list(range(iters)) if keep_p is None else [k for k in keep_p if k < iters]
+    tr["P_in_iters"] = np.array(keep, dtype=np.int32)
+    tr["P_in"] = tr["P_in"][keep]
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), P=P, Q=Q, iters=np.int32(iters), **tr)
+    print("%-14s N=%d M=%d iters=%d  -> %s.npz" % (name, len(P), len(Q), iters, name))
+
+
+def ties_clouds():
+    """Adversarial correspondence-only case (SURVEY.md 7.3 hard parts 1-2): inputs are used as-is
+    (already 'centred'), so exact and few-ulp ties survive."""
+    rng = np.random.RandomState(7)
+    P, Q = [], []
+    # (a) known answer: d^2 = {1+2^-52.., 1}: both fourth roots round to 1 -> the FIRST (farther) wins
+    P.append([0.0, 0.0, 0.0])
+    Q += [[np.nextafter(1.0, 2.0), 0.0, 0.0], [1.0, 0.0, 0.0]]
+    # (b) half-integer lattice: every p is exactly equidistant from 8 lattice points
+    g = np.arange(6, dtype=np.float64) * 0.5 + 3.0
+    lat = np.array([[x, y, z] for x in g for y in g for z in g])
+    Q += lat[rng.permutation(len(lat))].tolist()
+    P += (lat[:125] + 0.25).tolist()
+    # (c) exact duplicates in Q at scattered positions, and p's sitting exactly on them
+    off = np.array([0.0, 0.0, -50.0])   # keep this block away from the known-answer pair at the origin
+    dup = rng.uniform(-2, 2, size=(40, 3)) + off
+    Q += dup.tolist() + (rng.uniform(-2, 2, size=(100, 3)) + off).tolist() + dup[::-1].tolist()
+    P += dup.tolist()
+    # (d) candidates whose d^2 differ by 1..8 ulp, the slightly farther one listed first
+    for k in range(1, 9):
+        for _ in range(12):
+            p = rng.uniform(-1, 1, 3)
+            d = rng.uniform(0.5, 2.0)
+            q_near = p + np.array([d, 0, 0])
+            q_far = q_near.copy()
+            for _ in range(k):
+                q_far[0] = np.nextafter(q_far[0], 10.0)
+            Q += [(q_far + 20.0).tolist(), (q_near + 20.0).tolist()]
+            P.append((p + 20.0).tolist())
+    # (e) mirrored pairs about p (exact real-arithmetic ties along each axis)
+    for _ in range(60):
+        p = np.round(rng.uniform(-4, 4, 3) * 64) / 64 - 30.0
+        o = np.round(rng.uniform(0.1, 1, 3) * 64) / 64
+        Q += [(p + o).tolist(), (p - o).tolist(), (p + o * [1, -1, 1]).tolist(), (p - o * [1, -1, 1]).tolist()]
+        P.append(p.tolist())
+    return np.array(P, dtype=np.float64), np.array(Q, dtype=np.float64)
+
+
+def run_corr_case(name, Pz, Qz):
+    with tempfile.TemporaryDirectory() as td:
+        pf, qf, out = os.path.join(td, "P.csv"), os.path.join(td, "Q.csv"), os.path.join(td, "idx.bin")
+        write_csv(pf, Pz)
+        write_csv(qf, Qz)
+        subprocess.check_call([TRACE, "--corr", pf, qf, out])
+        idx = np.fromfile(out, dtype=np.int32)
+    assert len(idx) == len(Pz)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), Pz=Pz, Qz=Qz, idx=idx)
+    print("%-14s N=%d M=%d (correspondences only) -> %s.npz" % (name, len(Pz), len(Qz), name))
+
+
+def lattice_pair():
+    """Whole-loop case with structured exact ties: Q a 10x10x10 integer lattice (duplicated corner
+    points), P the same lattice rotated slightly and offset by half a cell."""
+    g = np.arange(10, dtype=np.float64)
+    Q = np.array([[x, y, z] for x in g for y in g for z in g])
+    Q = np.concatenate([Q, Q[:50]])
+    P = Q[:1000] @ synth.rotation(0.02).T + np.array([0.5, 0.5, 0.5])
+    P[:200] = Q[:200] + 0.5   # exact half-cell offsets: 8-way ties
+    return np.ascontiguousarray(P), np.ascontiguousarray(Q)
+
+
+CASES = {}
+
+
+def case(fn):
+    CASES[fn.__name__] = fn
+    return fn
+
+
+@case
+def c1_30pts():
+    pf, qf = REF + "/30points_notebook_P.txt", REF + "/30points_notebook_Q.txt"
+    run_icp_case("c1_30pts", load_csv(pf), load_csv(qf), 5, pfile=pf, qfile=qf)
+
+
+@case
+def cow_tr1():
+    pf, qf = REF + "/icp/cow_tr1.txt", REF + "/icp/cow_ref.txt"
+    run_icp_case("cow_tr1", load_csv(pf), load_csv(qf), 20, keep_p=[0, 1, 2, 10, 19], pfile=pf, qfile=qf)
+
+
+# (cow_tr2.txt has 5 columns: the reference aborts on it -- "element_wise_reduce requires arrays to be
+#  broadcastable" -- so it is an error-path case, not a golden one.)
+
+
+@case
+def horse_tr1():
+    pf, qf = REF + "/icp/horse_tr1.txt", REF + "/icp/horse_ref.txt"
+    run_icp_case("horse_tr1", load_csv(pf), load_csv(qf), 1, pfile=pf, qfile=qf)
+
+
+@case
+def bun045_000():
+    pf, qf = REF + "/icp/bun045.txt", REF + "/icp/bun000.txt"
+    run_icp_case("bun045_000", load_csv(pf), load_csv(qf), 1, pfile=pf, qfile=qf)
+
+
+@case
+def syn256():
+    P, Q = synth.make_pair(256, 256, seed=101)
+    run_icp_case("syn256", P, Q, 5)
+
+
+@case
+def syn1k():
+    P, Q = synth.make_pair(1000, 1000, seed=102)
+    run_icp_case("syn1k", P, Q, 5, keep_p=[0, 1, 4])
+
+
+@case
+def syn3k_4k():
+    P, Q = synth.make_pair(3000, 4099, seed=103)
+    run_icp_case("syn3k_4k", P, Q, 3, keep_p=[0, 2])
+
+
+@case
+def syn20k():
+    P, Q = synth.make_pair(20000, 20000, seed=104)
+    run_icp_case("syn20k", P, Q, 2, keep_p=[0, 1])
+
+
+@case
+def lattice():
+    P, Q = lattice_pair()
+    run_icp_case("lattice", P, Q, 3)
+
+
+@case
+def ties_corr():
+    Pz, Qz = ties_clouds()
+    run_corr_case("ties_corr", Pz, Qz)
+
+
+if __name__ == "__main__":
+    names = sys.argv[1:] or list(CASES)
+    for nm in names:
+        CASES[nm]()
