@@ -1,0 +1,216 @@
+"""icp_amd -- MI355X-native Iterative Closest Point engine (host-side mirror of the reference interface).
+
+The product is the C-ABI library icp_amd/libicp_amd.so (hand-written HIP kernels for gfx950, see
+include/icp_amd.h and DESIGN.md) and the GPUICP executable built on it.  This package is the thin Python
+face of that ABI used by the tests and bench.py; its function names follow the reference's C++ entry
+points (reference include/gpu/icp.cuh:38-39, include/libCSV/csv.hpp:33).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import METHODS, SEARCH, IcpAmdError, Options, Trace, check, lib
+
+__all__ = ["icp_gpu_optimized", "icp_gpu", "Engine", "read_csv", "write_cloud", "euclidian_distance",
+           "correspondences", "cross_cov", "centroid", "solve", "apply", "rows_per_rank", "chunks_per_rank",
+           "IcpAmdError", "device_count"]
+
+
+def _f64(a, cols=3):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if a.ndim != 2 or a.shape[1] != cols:
+        raise IcpAmdError(_lib.EINVAL, "expected an (n, %d) array, got %r" % (cols, a.shape))
+    return a
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def device_count():
+    return int(lib().icp_amd_device_count())
+
+
+def rows_per_rank(n_global, world):
+    return int(lib().icp_amd_rows_per_rank(n_global, world))
+
+
+def chunks_per_rank(n_global, world):
+    return int(lib().icp_amd_chunks_per_rank(n_global, world))
+
+
+def icp_gpu_optimized(P, Q, iterations, method="-shared-loop", trace=False):
+    """Mirror of icp_gpu_optimized(CPUMatrix&, CPUMatrix&, unsigned, std::string&) (reference
+    src/gpu/icp.cu:469-652).  Returns the registered cloud; with trace=True returns (P_out, dict)."""
+    if method not in METHODS:
+        raise IcpAmdError(_lib.EINVAL, "Invalid method, must be: -shared|-loop|-shared-loop|-batch")
+    P, Q = _f64(P), _f64(Q)
+    n = P.shape[0]
+    out = np.empty_like(P)
+    tr, d = None, None
+    if trace:
+        d = dict(Pc=np.empty((iterations, 3)), idx=np.empty((iterations, n), dtype=np.int32),
+                 cov=np.empty((iterations, 3, 3)), S=np.empty((iterations, 3)), R=np.empty((iterations, 3, 3)),
+                 t=np.empty((iterations, 3)), rms=np.empty(iterations))
+        tr = Trace(**{k: v.ctypes.data for k, v in d.items()})
+    check(lib().icp_amd_run(_p(P), C.c_size_t(n), _p(Q), C.c_size_t(Q.shape[0]), C.c_uint(iterations),
+                            C.c_int(METHODS[method]), _p(out), C.byref(tr) if tr is not None else None))
+    return (out, d) if trace else out
+
+
+def icp_gpu(P, Q, iterations, trace=False):
+    """Mirror of icp_gpu(CPUMatrix&, CPUMatrix&, unsigned) (reference src/gpu/icp.cu:275-445, `-batch`)."""
+    return icp_gpu_optimized(P, Q, iterations, "-batch", trace=trace)
+
+
+class Engine:
+    """Persistent device-resident engine (icp_amd_create ... icp_amd_destroy)."""
+
+    def __init__(self, device=0, stream=None, search="auto", q_splits=0, kernel_timing=False, rank=0, world=1,
+                 n_global=0, cov_gather=None, cen_gather=None):
+        o = Options()
+        lib().icp_amd_default_options(C.byref(o))
+        o.device, o.stream, o.search, o.q_splits = device, stream, SEARCH[search], q_splits
+        o.kernel_timing, o.rank, o.world, o.n_global = int(kernel_timing), rank, world, n_global
+        o.cov_gather, o.cen_gather = cov_gather, cen_gather
+        self._h = C.c_void_p()
+        self.n = 0
+        check(lib().icp_amd_create(C.byref(self._h), C.byref(o)))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().icp_amd_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def set_target(self, Q):
+        Q = _f64(Q)
+        check(lib().icp_amd_set_target(self._h, _p(Q), C.c_size_t(Q.shape[0])))
+
+    def set_source(self, P):
+        P = _f64(P)
+        self.n = P.shape[0]
+        check(lib().icp_amd_set_source(self._h, _p(P), C.c_size_t(self.n)))
+
+    def iterate(self, iters):
+        check(lib().icp_amd_iterate(self._h, C.c_uint(iters)))
+
+    def iterate_timed(self, iters):
+        ms = C.c_double()
+        check(lib().icp_amd_iterate_timed(self._h, C.c_uint(iters), C.byref(ms)))
+        return ms.value
+
+    def step_begin(self):
+        check(lib().icp_amd_step_begin(self._h))
+
+    def step_search(self):
+        check(lib().icp_amd_step_search(self._h))
+
+    def step_update(self):
+        check(lib().icp_amd_step_update(self._h))
+
+    def sync(self):
+        check(lib().icp_amd_sync(self._h))
+
+    def get_source(self):
+        out = np.empty((self.n, 3))
+        check(lib().icp_amd_get_source(self._h, _p(out)))
+        return out
+
+    def get_last(self):
+        d = dict(Pc=np.empty(3), idx=np.empty(self.n, dtype=np.int32), cov=np.empty((3, 3)), S=np.empty(3),
+                 R=np.empty((3, 3)), t=np.empty(3))
+        rms = C.c_double()
+        check(lib().icp_amd_get_last(self._h, _p(d["Pc"]), _p(d["idx"]), _p(d["cov"]), _p(d["S"]), _p(d["R"]),
+                                     _p(d["t"]), C.byref(rms)))
+        d["rms"] = rms.value
+        return d
+
+    def target_centroid(self):
+        qc = np.empty(3)
+        check(lib().icp_amd_get_target_centroid(self._h, _p(qc)))
+        return qc
+
+    def kernel_ms(self):
+        avg, tot, cnt = C.c_double(), C.c_double(), C.c_uint()
+        check(lib().icp_amd_kernel_ms(self._h, C.byref(avg), C.byref(tot), C.byref(cnt)))
+        return avg.value, tot.value, cnt.value
+
+    def search_geometry(self):
+        a, b, c, d = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        check(lib().icp_amd_search_geometry(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
+        return dict(points_per_lane=a.value, q_splits=b.value, workgroups=c.value,
+                    variant={1: "exact", 2: "fma"}.get(d.value, str(d.value)))
+
+
+# ---- stage level (parity tests) --------------------------------------------------------------------
+def correspondences(P, Pc, Qz, search="exact", q_splits=1):
+    P, Qz = _f64(P), _f64(Qz)
+    Pc = np.ascontiguousarray(Pc, dtype=np.float64)
+    idx = np.empty(P.shape[0], dtype=np.int32)
+    check(lib().icp_amd_correspondences(_p(P), C.c_size_t(P.shape[0]), _p(Pc), _p(Qz), C.c_size_t(Qz.shape[0]),
+                                        C.c_int(SEARCH[search]), C.c_int(q_splits), _p(idx)))
+    return idx
+
+
+def cross_cov(P, Pc, Qz, idx):
+    P, Qz = _f64(P), _f64(Qz)
+    Pc = np.ascontiguousarray(Pc, dtype=np.float64)
+    idx = np.ascontiguousarray(idx, dtype=np.int32)
+    cov = np.empty((3, 3))
+    check(lib().icp_amd_cross_cov(_p(P), C.c_size_t(P.shape[0]), _p(Pc), _p(Qz), C.c_size_t(Qz.shape[0]), _p(idx), _p(cov)))
+    return cov
+
+
+def centroid(A):
+    A = _f64(A)
+    out = np.empty(3)
+    check(lib().icp_amd_centroid(_p(A), C.c_size_t(A.shape[0]), _p(out)))
+    return out
+
+
+def solve(cov, Pc, Qc):
+    cov = np.ascontiguousarray(cov, dtype=np.float64).reshape(9)
+    Pc = np.ascontiguousarray(Pc, dtype=np.float64)
+    Qc = np.ascontiguousarray(Qc, dtype=np.float64)
+    R, t, S = np.empty((3, 3)), np.empty(3), np.empty(3)
+    check(lib().icp_amd_solve(_p(cov), _p(Pc), _p(Qc), _p(R), _p(t), _p(S)))
+    return R, t, S
+
+
+def apply(P, R, t):
+    P = _f64(P)
+    R = np.ascontiguousarray(R, dtype=np.float64).reshape(9)
+    t = np.ascontiguousarray(t, dtype=np.float64)
+    out = np.empty_like(P)
+    check(lib().icp_amd_apply(_p(P), C.c_size_t(P.shape[0]), _p(R), _p(t), _p(out)))
+    return out
+
+
+# ---- host I/O kept from the reference ---------------------------------------------------------------
+def read_csv(path):
+    """readCSV (reference src/libCSV/csv.cpp:94-158): returns (array[nblines, nbcols], header)."""
+    out = C.POINTER(C.c_double)()
+    nl, nc = C.c_size_t(), C.c_size_t()
+    hdr = C.create_string_buffer(4096)
+    check(lib().icp_amd_read_csv(str(path).encode(), C.byref(out), C.byref(nl), C.byref(nc), hdr, C.c_size_t(4096)))
+    try:
+        a = np.ctypeslib.as_array(out, shape=(nl.value * nc.value,)).copy() if nl.value * nc.value else np.empty(0)
+    finally:
+        lib().icp_amd_free(out)
+    return a.reshape(nl.value, nc.value), hdr.value.decode(errors="replace")
+
+
+def write_cloud(path, A):
+    A = np.ascontiguousarray(A, dtype=np.float64)
+    check(lib().icp_amd_write_cloud(str(path).encode(), _p(A), C.c_size_t(A.shape[0]), C.c_size_t(A.shape[1])))
+
+
+def euclidian_distance(A, B):
+    A = np.ascontiguousarray(A, dtype=np.float64)
+    B = np.ascontiguousarray(B, dtype=np.float64)
+    if A.shape != B.shape:
+        raise IcpAmdError(_lib.EINVAL, "element_wise_reduce requires arrays to be broadcastable")
+    return float(lib().icp_amd_euclidian_distance(_p(A), _p(B), C.c_size_t(A.shape[0]), C.c_size_t(A.shape[1])))

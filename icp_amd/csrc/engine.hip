@@ -1,0 +1,708 @@
+// icp_amd/csrc/engine.hip -- host side of libicp_amd.so: the device-resident ICP engine and the C ABI
+// declared in include/icp_amd.h.  Replaces the driver of the reference GPU path (src/gpu/icp.cu:469-652):
+// buffers are allocated once, every iteration is five stream-ordered launches and no host sync.
+#include "../../include/icp_amd.h"
+#include "kernels.h"
+
+#include <hip/hip_runtime.h>
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <limits>
+#include <new>
+#include <vector>
+
+using namespace icpk;
+
+// ------------------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------------------
+extern "C" int icp_amd_fail_(int code, const char *fmt, ...);  // hostio.cpp: sets the thread-local error text
+#define fail icp_amd_fail_
+
+#define HIPCHK(expr)                                                                                          \
+    do {                                                                                                      \
+        hipError_t e_ = (expr);                                                                               \
+        if (e_ != hipSuccess)                                                                                 \
+            return fail(e_ == hipErrorOutOfMemory ? ICP_AMD_ENOMEM : ICP_AMD_EHIP, "HIP failure %s:%d '%s' in %s", \
+                        __FILE__, __LINE__, hipGetErrorString(e_), #expr);                                    \
+    } while (0)
+
+#define RCCHK(expr)               \
+    do {                          \
+        int rc_ = (expr);         \
+        if (rc_ != ICP_AMD_OK) return rc_; \
+    } while (0)
+
+extern "C" int icp_amd_version(void) { return 100; }
+
+extern "C" int icp_amd_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+static int require_device(int device)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(ICP_AMD_ENODEV, "no HIP device available (%s); libicp_amd has no CPU fallback",
+                    e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+    if (device < 0 || device >= n) return fail(ICP_AMD_EINVAL, "device %d out of range [0,%d)", device, n);
+    HIPCHK(hipSetDevice(device));
+    return ICP_AMD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// sharding arithmetic
+// ------------------------------------------------------------------------------------------------
+static size_t round_up(size_t v, size_t m) { return (v + m - 1) / m * m; }
+
+extern "C" size_t icp_amd_chunks_per_rank(size_t n_global, int world)
+{
+    if (world < 1) world = 1;
+    const size_t chunks = (n_global + kChunk - 1) / kChunk;
+    return (chunks + (size_t)world - 1) / (size_t)world;
+}
+
+extern "C" size_t icp_amd_rows_per_rank(size_t n_global, int world)
+{
+    return icp_amd_chunks_per_rank(n_global, world) * kChunk;
+}
+
+extern "C" void icp_amd_default_options(icp_amd_options *opt)
+{
+    if (!opt) return;
+    memset(opt, 0, sizeof *opt);
+    opt->world = 1;
+}
+
+// ------------------------------------------------------------------------------------------------
+// engine
+// ------------------------------------------------------------------------------------------------
+struct icp_amd_engine {
+    icp_amd_options opt;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int cu_count = 256;
+
+    // target
+    size_t m = 0, m_pad = 0;
+    double *q_store = nullptr;  // 3 * m_pad
+    Soa3 Qz{nullptr, nullptr, nullptr};
+    double *qc = nullptr;       // 3
+
+    // source (local rows)
+    size_t n = 0, n_pad = 0, n_global = 0;
+    size_t chunks_local = 0, cpr = 0, total_chunks = 0;
+    double *p_store = nullptr;  // 3 * n_pad
+    Soa3 P{nullptr, nullptr, nullptr};
+    double *pc = nullptr;       // 3
+
+    double *stage = nullptr;    // AoS staging for uploads / downloads
+    size_t stage_rows = 0;
+
+    // search
+    int variant = kExact, ppl = 4, q_splits = 1;
+    double *keys = nullptr;
+    uint32_t *idxs = nullptr;
+    size_t split_cap = 0;       // allocated q_splits * n_pad
+    uint32_t *idx = nullptr;    // n_pad
+
+    // partials
+    double *cov_part = nullptr, *cen_part = nullptr;  // world*cpr*{12,3}; own or caller's gather buffers
+    bool own_part = false;
+    double *rec = nullptr;      // kSolveW doubles: outputs of the most recent solve
+
+    bool have_target = false, have_source = false, cen_ready = false;
+
+    // timing of the search launches
+    std::vector<hipEvent_t> ev;  // pairs
+    size_t ev_used = 0;
+    double search_ms_total = 0;
+    unsigned search_launches = 0;
+};
+
+static void free_dev(void *p) { if (p) (void)hipFree(p); }
+
+static int env_int(const char *name, int dflt)
+{
+    const char *v = getenv(name);
+    if (!v || !*v) return dflt;
+    return atoi(v);
+}
+
+extern "C" int icp_amd_create(icp_amd_engine **out, const icp_amd_options *opt_in)
+{
+    if (!out) return fail(ICP_AMD_EINVAL, "icp_amd_create: out is NULL");
+    *out = nullptr;
+    icp_amd_options opt;
+    if (opt_in) opt = *opt_in; else icp_amd_default_options(&opt);
+    if (opt.world < 1) opt.world = 1;
+    if (opt.rank < 0 || opt.rank >= opt.world) return fail(ICP_AMD_EINVAL, "rank %d not in [0,%d)", opt.rank, opt.world);
+    if (opt.world > 1 && (!opt.cov_gather || !opt.cen_gather || opt.n_global == 0))
+        return fail(ICP_AMD_EINVAL, "world > 1 needs cov_gather, cen_gather and n_global");
+    RCCHK(require_device(opt.device));
+    icp_amd_engine *e = new (std::nothrow) icp_amd_engine();
+    if (!e) return fail(ICP_AMD_ENOMEM, "out of host memory");
+    e->opt = opt;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, opt.device) == hipSuccess && prop.multiProcessorCount > 0)
+        e->cu_count = prop.multiProcessorCount;
+    if (opt.stream) {
+        e->stream = (hipStream_t)opt.stream;
+    } else {
+        hipError_t er = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
+        if (er != hipSuccess) { delete e; return fail(ICP_AMD_EHIP, "hipStreamCreate: %s", hipGetErrorString(er)); }
+        e->own_stream = true;
+    }
+    hipError_t er = hipMalloc(&e->qc, 3 * sizeof(double));
+    if (er == hipSuccess) er = hipMalloc(&e->pc, 3 * sizeof(double));
+    if (er == hipSuccess) er = hipMalloc(&e->rec, kSolveW * sizeof(double));
+    if (er != hipSuccess) { icp_amd_destroy(e); return fail(ICP_AMD_ENOMEM, "hipMalloc: %s", hipGetErrorString(er)); }
+    *out = e;
+    return ICP_AMD_OK;
+}
+
+extern "C" int icp_amd_destroy(icp_amd_engine *e)
+{
+    if (!e) return ICP_AMD_OK;
+    (void)hipSetDevice(e->opt.device);
+    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    for (hipEvent_t ev : e->ev) (void)hipEventDestroy(ev);
+    free_dev(e->q_store); free_dev(e->qc); free_dev(e->p_store); free_dev(e->pc); free_dev(e->stage);
+    free_dev(e->keys); free_dev(e->idxs); free_dev(e->idx); free_dev(e->rec);
+    if (e->own_part) { free_dev(e->cov_part); free_dev(e->cen_part); }
+    if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
+    delete e;
+    return ICP_AMD_OK;
+}
+
+static int ensure_stage(icp_amd_engine *e, size_t rows)
+{
+    if (rows <= e->stage_rows) return ICP_AMD_OK;
+    free_dev(e->stage);
+    e->stage = nullptr;
+    e->stage_rows = 0;
+    HIPCHK(hipMalloc(&e->stage, rows * 3 * sizeof(double)));
+    e->stage_rows = rows;
+    return ICP_AMD_OK;
+}
+
+static const size_t kMaxRows = 0x7FFFFC00u;  // indices are 32-bit; padded sizes must fit too
+
+extern "C" int icp_amd_set_target(icp_amd_engine *e, const double *Q, size_t m)
+{
+    if (!e || !Q) return fail(ICP_AMD_EINVAL, "icp_amd_set_target: NULL argument");
+    if (m == 0) return fail(ICP_AMD_EINVAL, "target cloud is empty");
+    if (m > kMaxRows) return fail(ICP_AMD_EINVAL, "target cloud too large (%zu rows, limit %zu)", m, kMaxRows);
+    HIPCHK(hipSetDevice(e->opt.device));
+    const size_t m_pad = round_up(m, kTileQ);
+    if (m_pad != e->m_pad) {
+        free_dev(e->q_store);
+        e->q_store = nullptr;
+        e->m_pad = 0;
+        HIPCHK(hipMalloc(&e->q_store, 3 * m_pad * sizeof(double)));
+        e->m_pad = m_pad;
+        e->Qz = Soa3{e->q_store, e->q_store + m_pad, e->q_store + 2 * m_pad};
+    }
+    e->m = m;
+    RCCHK(ensure_stage(e, m));
+    HIPCHK(hipMemcpyAsync(e->stage, Q, m * 3 * sizeof(double), hipMemcpyHostToDevice, e->stream));
+    // Q_center = Q.mean(0); Q -= Q_center (reference src/cpu/icp.cpp:197-198), then SoA + inf padding
+    const size_t chunks = (m + kChunk - 1) / kChunk;
+    double *part = nullptr;
+    HIPCHK(hipMalloc(&part, chunks * kCenW * sizeof(double)));
+    hipError_t er = colsum_partials(e->stream, e->stage, Soa3{nullptr, nullptr, nullptr}, m, part);
+    if (er == hipSuccess) er = finalize_centroid(e->stream, part, chunks, (double)m, e->qc);
+    if (er == hipSuccess)
+        er = aos_to_soa(e->stream, e->stage, m, m_pad, e->qc, std::numeric_limits<double>::infinity(), e->Qz);
+    if (er == hipSuccess) er = hipStreamSynchronize(e->stream);
+    (void)hipFree(part);
+    HIPCHK(er);
+    e->have_target = true;
+    return ICP_AMD_OK;
+}
+
+// Launch geometry of the search kernel: enough workgroups to load every CU several times over, without
+// cutting the target range into pieces so short that every piece re-learns its running minimum.
+static void choose_geometry(icp_amd_engine *e)
+{
+    int ppl = 4;
+    const size_t cus = (size_t)e->cu_count;
+    if (e->n_pad / (kWG * 4) < 2 * cus) ppl = 2;
+    if (e->n_pad / (kWG * 2) < 2 * cus) ppl = 1;
+    ppl = env_int("ICP_AMD_PPL", ppl);
+    if (ppl != 1 && ppl != 2 && ppl != 4) ppl = 4;
+    const size_t ptiles = e->n_pad / ((size_t)kWG * ppl);
+    const size_t tiles = e->m_pad / kTileQ;
+    size_t splits = 1;
+    const size_t want = 8 * cus;
+    if (ptiles < want) splits = (want + ptiles - 1) / ptiles;
+    if (splits > tiles / 2) splits = tiles / 2;   // at least two LDS tiles per split
+    if (splits > 64) splits = 64;
+    if (splits < 1) splits = 1;
+    if (e->opt.q_splits > 0) splits = (size_t)e->opt.q_splits;
+    splits = (size_t)env_int("ICP_AMD_QSPLITS", (int)splits);
+    if (splits < 1) splits = 1;
+    if (splits > tiles) splits = tiles;
+    e->ppl = ppl;
+    e->q_splits = (int)splits;
+    int variant = e->opt.search == ICP_AMD_SEARCH_FMA ? kFma : kExact;
+    const char *sv = getenv("ICP_AMD_SEARCH");
+    if (sv && !strcmp(sv, "fma")) variant = kFma;
+    if (sv && !strcmp(sv, "exact")) variant = kExact;
+    e->variant = variant;
+}
+
+extern "C" int icp_amd_set_source(icp_amd_engine *e, const double *P, size_t n)
+{
+    if (!e || (!P && n)) return fail(ICP_AMD_EINVAL, "icp_amd_set_source: NULL argument");
+    if (!e->have_target) return fail(ICP_AMD_ESTATE, "icp_amd_set_source: call icp_amd_set_target first");
+    const int world = e->opt.world;
+    const size_t n_global = (world > 1) ? e->opt.n_global : (e->opt.n_global ? e->opt.n_global : n);
+    if (n_global == 0) return fail(ICP_AMD_EINVAL, "source cloud is empty");
+    if (n_global > kMaxRows) return fail(ICP_AMD_EINVAL, "source cloud too large (%zu rows, limit %zu)", n_global, kMaxRows);
+    const size_t cpr = icp_amd_chunks_per_rank(n_global, world);
+    const size_t first = (size_t)e->opt.rank * cpr * kChunk;
+    const size_t expect = first >= n_global ? 0 : ((n_global - first < cpr * kChunk) ? n_global - first : cpr * kChunk);
+    if (n != expect)
+        return fail(ICP_AMD_EINVAL, "rank %d of %d must own %zu source rows (got %zu)", e->opt.rank, world, expect, n);
+    HIPCHK(hipSetDevice(e->opt.device));
+    const size_t n_pad = round_up(n ? n : 1, kChunk);
+    if (n_pad != e->n_pad) {
+        free_dev(e->p_store); free_dev(e->idx);
+        e->p_store = nullptr; e->idx = nullptr; e->n_pad = 0;
+        HIPCHK(hipMalloc(&e->p_store, 3 * n_pad * sizeof(double)));
+        HIPCHK(hipMalloc(&e->idx, n_pad * sizeof(uint32_t)));
+        e->n_pad = n_pad;
+        e->P = Soa3{e->p_store, e->p_store + n_pad, e->p_store + 2 * n_pad};
+    }
+    e->n = n;
+    e->n_global = n_global;
+    e->cpr = cpr;
+    e->chunks_local = (n + kChunk - 1) / kChunk;
+    const size_t total = cpr * (size_t)world;
+    if (world > 1) {
+        e->cov_part = e->opt.cov_gather;
+        e->cen_part = e->opt.cen_gather;
+        e->own_part = false;
+    } else if (total != e->total_chunks || !e->own_part) {
+        if (e->own_part) { free_dev(e->cov_part); free_dev(e->cen_part); }
+        e->cov_part = e->cen_part = nullptr;
+        HIPCHK(hipMalloc(&e->cov_part, total * kCovW * sizeof(double)));
+        HIPCHK(hipMalloc(&e->cen_part, total * kCenW * sizeof(double)));
+        e->own_part = true;
+    }
+    e->total_chunks = total;
+    choose_geometry(e);
+    const size_t need = (size_t)e->q_splits * n_pad;
+    if (need > e->split_cap) {
+        free_dev(e->keys); free_dev(e->idxs);
+        e->keys = nullptr; e->idxs = nullptr; e->split_cap = 0;
+        HIPCHK(hipMalloc(&e->keys, need * sizeof(double)));
+        HIPCHK(hipMalloc(&e->idxs, need * sizeof(uint32_t)));
+        e->split_cap = need;
+    }
+    // this rank's slots of the partial arrays: unused trailing records stay zero for the whole run
+    double *cov_slot = e->cov_part + (size_t)e->opt.rank * cpr * kCovW;
+    double *cen_slot = e->cen_part + (size_t)e->opt.rank * cpr * kCenW;
+    HIPCHK(hipMemsetAsync(cov_slot, 0, cpr * kCovW * sizeof(double), e->stream));
+    HIPCHK(hipMemsetAsync(cen_slot, 0, cpr * kCenW * sizeof(double), e->stream));
+    if (n) {
+        RCCHK(ensure_stage(e, n));
+        HIPCHK(hipMemcpyAsync(e->stage, P, n * 3 * sizeof(double), hipMemcpyHostToDevice, e->stream));
+    }
+    HIPCHK(aos_to_soa(e->stream, e->stage, n, n_pad, nullptr, 0.0, e->P));
+    HIPCHK(hipStreamSynchronize(e->stream));  // P may be reused by the caller after return
+    e->have_source = true;
+    e->cen_ready = false;
+    return ICP_AMD_OK;
+}
+
+extern "C" int icp_amd_step_begin(icp_amd_engine *e)
+{
+    if (!e || !e->have_source) return fail(ICP_AMD_ESTATE, "icp_amd_step_begin: no source cloud");
+    HIPCHK(hipSetDevice(e->opt.device));
+    double *cen_slot = e->cen_part + (size_t)e->opt.rank * e->cpr * kCenW;
+    HIPCHK(colsum_partials(e->stream, nullptr, e->P, e->n, cen_slot));
+    e->cen_ready = true;
+    return ICP_AMD_OK;
+}
+
+static int time_begin(icp_amd_engine *e, hipEvent_t *a, hipEvent_t *b)
+{
+    if (e->ev_used + 2 > e->ev.size()) {
+        hipEvent_t x, y;
+        HIPCHK(hipEventCreate(&x));
+        HIPCHK(hipEventCreate(&y));
+        e->ev.push_back(x);
+        e->ev.push_back(y);
+    }
+    *a = e->ev[e->ev_used];
+    *b = e->ev[e->ev_used + 1];
+    e->ev_used += 2;
+    HIPCHK(hipEventRecord(*a, e->stream));
+    return ICP_AMD_OK;
+}
+
+static int drain_events(icp_amd_engine *e)
+{
+    for (size_t k = 0; k + 1 < e->ev_used; k += 2) {
+        HIPCHK(hipEventSynchronize(e->ev[k + 1]));
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, e->ev[k], e->ev[k + 1]));
+        e->search_ms_total += ms;
+        e->search_launches += 1;
+    }
+    e->ev_used = 0;
+    return ICP_AMD_OK;
+}
+
+extern "C" int icp_amd_step_search(icp_amd_engine *e)
+{
+    if (!e || !e->have_source) return fail(ICP_AMD_ESTATE, "icp_amd_step_search: no source cloud");
+    if (!e->cen_ready) return fail(ICP_AMD_ESTATE, "icp_amd_step_search: centroid partials missing (step_begin / step_update first)");
+    HIPCHK(hipSetDevice(e->opt.device));
+    // P_center = P_copy.mean(0) (src/cpu/icp.cpp:206): chunk partials of every rank, summed in index order
+    HIPCHK(finalize_centroid(e->stream, e->cen_part, e->total_chunks, (double)e->n_global, e->pc));
+    double *cov_slot = e->cov_part + (size_t)e->opt.rank * e->cpr * kCovW;
+    if (e->n) {
+        hipEvent_t a = nullptr, b = nullptr;
+        if (e->opt.kernel_timing) {
+            if (e->ev_used >= 4096) RCCHK(drain_events(e));
+            RCCHK(time_begin(e, &a, &b));
+        }
+        HIPCHK(search(e->stream, e->variant, e->ppl, e->P, e->n_pad, e->pc, e->Qz, e->m_pad, e->q_splits, e->keys, e->idxs));
+        if (e->opt.kernel_timing) HIPCHK(hipEventRecord(b, e->stream));
+        HIPCHK(merge_cov(e->stream, e->P, e->n, e->n_pad, e->pc, e->Qz, e->m, e->q_splits, e->keys, e->idxs, e->idx, cov_slot));
+    }
+    return ICP_AMD_OK;
+}
+
+extern "C" int icp_amd_step_update(icp_amd_engine *e)
+{
+    if (!e || !e->have_source) return fail(ICP_AMD_ESTATE, "icp_amd_step_update: no source cloud");
+    HIPCHK(hipSetDevice(e->opt.device));
+    HIPCHK(solve(e->stream, e->cov_part, e->total_chunks, e->pc, e->qc, (double)e->n_global, e->rec));
+    double *cen_slot = e->cen_part + (size_t)e->opt.rank * e->cpr * kCenW;
+    HIPCHK(apply(e->stream, e->P, e->n, e->rec, cen_slot));
+    return ICP_AMD_OK;
+}
+
+extern "C" int icp_amd_iterate(icp_amd_engine *e, unsigned iters)
+{
+    if (!e) return fail(ICP_AMD_EINVAL, "icp_amd_iterate: NULL engine");
+    if (e->opt.world != 1) return fail(ICP_AMD_ESTATE, "icp_amd_iterate needs world == 1; use the step_* calls when sharded");
+    if (!e->have_source) return fail(ICP_AMD_ESTATE, "icp_amd_iterate: no source cloud");
+    if (iters && !e->cen_ready) RCCHK(icp_amd_step_begin(e));
+    for (unsigned it = 0; it < iters; ++it) {
+        RCCHK(icp_amd_step_search(e));
+        RCCHK(icp_amd_step_update(e));
+    }
+    return ICP_AMD_OK;
+}
+
+extern "C" int icp_amd_iterate_timed(icp_amd_engine *e, unsigned iters, double *elapsed_ms)
+{
+    if (!e) return fail(ICP_AMD_EINVAL, "icp_amd_iterate_timed: NULL engine");
+    HIPCHK(hipSetDevice(e->opt.device));
+    if (iters && !e->cen_ready && e->have_source) RCCHK(icp_amd_step_begin(e));
+    hipEvent_t a, b;
+    HIPCHK(hipEventCreate(&a));
+    HIPCHK(hipEventCreate(&b));
+    int rc = ICP_AMD_OK;
+    hipError_t er = hipEventRecord(a, e->stream);
+    if (er == hipSuccess) rc = icp_amd_iterate(e, iters);
+    if (er == hipSuccess && rc == ICP_AMD_OK) er = hipEventRecord(b, e->stream);
+    if (er == hipSuccess && rc == ICP_AMD_OK) er = hipEventSynchronize(b);
+    float ms = 0;
+    if (er == hipSuccess && rc == ICP_AMD_OK) er = hipEventElapsedTime(&ms, a, b);
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+    RCCHK(rc);
+    HIPCHK(er);
+    if (elapsed_ms) *elapsed_ms = ms;
+    return ICP_AMD_OK;
+}
+
+extern "C" int icp_amd_sync(icp_amd_engine *e)
+{
+    if (!e) return fail(ICP_AMD_EINVAL, "icp_amd_sync: NULL engine");
+    HIPCHK(hipSetDevice(e->opt.device));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return ICP_AMD_OK;
+}
+
+extern "C" int icp_amd_get_source(icp_amd_engine *e, double *P_out)
+{
+    if (!e || (!P_out && e->n)) return fail(ICP_AMD_EINVAL, "icp_amd_get_source: NULL argument");
+    if (!e->have_source) return fail(ICP_AMD_ESTATE, "icp_amd_get_source: no source cloud");
+    HIPCHK(hipSetDevice(e->opt.device));
+    if (e->n) {
+        RCCHK(ensure_stage(e, e->n));
+        HIPCHK(soa_to_aos(e->stream, e->P, e->n, e->stage));
+        HIPCHK(hipMemcpyAsync(P_out, e->stage, e->n * 3 * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+    }
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return ICP_AMD_OK;
+}
+
+extern "C" int icp_amd_get_last(icp_amd_engine *e, double *Pc, int32_t *idx, double *cov, double *S, double *R, double *t,
+                                double *rms)
+{
+    if (!e) return fail(ICP_AMD_EINVAL, "icp_amd_get_last: NULL engine");
+    HIPCHK(hipSetDevice(e->opt.device));
+    double rec[kSolveW];
+    HIPCHK(hipMemcpyAsync(rec, e->rec, sizeof rec, hipMemcpyDeviceToHost, e->stream));
+    if (idx && e->n) HIPCHK(hipMemcpyAsync(idx, e->idx, e->n * sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    if (cov) memcpy(cov, rec, 9 * sizeof(double));
+    if (S) memcpy(S, rec + 9, 3 * sizeof(double));
+    if (R) memcpy(R, rec + 12, 9 * sizeof(double));
+    if (t) memcpy(t, rec + 21, 3 * sizeof(double));
+    if (rms) *rms = rec[24];
+    if (Pc) memcpy(Pc, rec + 25, 3 * sizeof(double));
+    return ICP_AMD_OK;
+}
+
+extern "C" int icp_amd_get_target_centroid(icp_amd_engine *e, double Qc[3])
+{
+    if (!e || !Qc || !e->have_target) return fail(ICP_AMD_ESTATE, "icp_amd_get_target_centroid: no target cloud");
+    HIPCHK(hipSetDevice(e->opt.device));
+    HIPCHK(hipMemcpyAsync(Qc, e->qc, 3 * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return ICP_AMD_OK;
+}
+
+extern "C" int icp_amd_kernel_ms(icp_amd_engine *e, double *avg_ms, double *total_ms, unsigned *launches)
+{
+    if (!e) return fail(ICP_AMD_EINVAL, "icp_amd_kernel_ms: NULL engine");
+    HIPCHK(hipSetDevice(e->opt.device));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    RCCHK(drain_events(e));
+    if (avg_ms) *avg_ms = e->search_launches ? e->search_ms_total / e->search_launches : 0.0;
+    if (total_ms) *total_ms = e->search_ms_total;
+    if (launches) *launches = e->search_launches;
+    e->search_ms_total = 0;
+    e->search_launches = 0;
+    return ICP_AMD_OK;
+}
+
+extern "C" int icp_amd_search_geometry(icp_amd_engine *e, int *ppl, int *q_splits, int *workgroups, int *variant)
+{
+    if (!e || !e->have_source) return fail(ICP_AMD_ESTATE, "icp_amd_search_geometry: no source cloud");
+    if (ppl) *ppl = e->ppl;
+    if (q_splits) *q_splits = e->q_splits;
+    if (workgroups) *workgroups = (int)(e->n_pad / ((size_t)kWG * e->ppl)) * e->q_splits;
+    if (variant) *variant = e->variant;
+    return ICP_AMD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// whole path
+// ------------------------------------------------------------------------------------------------
+extern "C" int icp_amd_run(const double *P, size_t n, const double *Q, size_t m, unsigned iters, int method, double *P_out,
+                           icp_amd_trace *tr)
+{
+    if (!P || !Q || !P_out) return fail(ICP_AMD_EINVAL, "icp_amd_run: NULL argument");
+    if (n == 0 || m == 0) return fail(ICP_AMD_EINVAL, "icp_amd_run: empty cloud (n=%zu, m=%zu)", n, m);
+    if (method < ICP_AMD_METHOD_SHARED_LOOP || method > ICP_AMD_METHOD_BATCH)
+        return fail(ICP_AMD_EINVAL, "Invalid method, must be: -shared|-loop|-shared-loop|-batch");
+    icp_amd_options opt;
+    icp_amd_default_options(&opt);
+    opt.device = env_int("ICP_AMD_DEVICE", 0);
+    icp_amd_engine *e = nullptr;
+    RCCHK(icp_amd_create(&e, &opt));
+    int rc = icp_amd_set_target(e, Q, m);
+    if (rc == ICP_AMD_OK) rc = icp_amd_set_source(e, P, n);
+    const bool tracing = tr && (tr->Pc || tr->idx || tr->cov || tr->S || tr->R || tr->t || tr->rms);
+    if (rc == ICP_AMD_OK) {
+        if (!tracing) {
+            rc = icp_amd_iterate(e, iters);
+        } else {
+            for (unsigned it = 0; it < iters && rc == ICP_AMD_OK; ++it) {
+                rc = icp_amd_iterate(e, 1);
+                if (rc == ICP_AMD_OK)
+                    rc = icp_amd_get_last(e, tr->Pc ? tr->Pc + 3 * it : nullptr, tr->idx ? tr->idx + (size_t)it * n : nullptr,
+                                          tr->cov ? tr->cov + 9 * it : nullptr, tr->S ? tr->S + 3 * it : nullptr,
+                                          tr->R ? tr->R + 9 * it : nullptr, tr->t ? tr->t + 3 * it : nullptr,
+                                          tr->rms ? tr->rms + it : nullptr);
+            }
+        }
+    }
+    if (rc == ICP_AMD_OK) rc = icp_amd_get_source(e, P_out);
+    icp_amd_destroy(e);
+    return rc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// stage-level entry points (parity tests)
+// ------------------------------------------------------------------------------------------------
+namespace {
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 8); }
+    template <class T> T *as() { return (T *)p; }
+};
+
+// upload a row-major host cloud into a padded SoA device buffer
+int upload_soa(hipStream_t s, const double *host, size_t n, size_t n_pad, double pad, DevBuf &store, DevBuf &stage, Soa3 &out)
+{
+    HIPCHK(store.alloc(3 * n_pad * sizeof(double)));
+    HIPCHK(stage.alloc(n * 3 * sizeof(double)));
+    if (n) HIPCHK(hipMemcpyAsync(stage.p, host, n * 3 * sizeof(double), hipMemcpyHostToDevice, s));
+    out = Soa3{store.as<double>(), store.as<double>() + n_pad, store.as<double>() + 2 * n_pad};
+    HIPCHK(aos_to_soa(s, stage.as<double>(), n, n_pad, nullptr, pad, out));
+    return ICP_AMD_OK;
+}
+}  // namespace
+
+extern "C" int icp_amd_correspondences(const double *P, size_t n, const double Pc[3], const double *Qz, size_t m, int search_variant,
+                                       int q_splits, int32_t *idx)
+{
+    if (!P || !Pc || !Qz || !idx) return fail(ICP_AMD_EINVAL, "icp_amd_correspondences: NULL argument");
+    if (n == 0 || m == 0 || n > kMaxRows || m > kMaxRows) return fail(ICP_AMD_EINVAL, "icp_amd_correspondences: bad sizes");
+    RCCHK(require_device(env_int("ICP_AMD_DEVICE", 0)));
+    hipStream_t s = nullptr;
+    const size_t n_pad = round_up(n, kChunk), m_pad = round_up(m, kTileQ);
+    DevBuf pst, pstage, qst, qstage, pc, keys, idxs, out, part;
+    Soa3 dP, dQ;
+    RCCHK(upload_soa(s, P, n, n_pad, 0.0, pst, pstage, dP));
+    RCCHK(upload_soa(s, Qz, m, m_pad, std::numeric_limits<double>::infinity(), qst, qstage, dQ));
+    HIPCHK(pc.alloc(3 * sizeof(double)));
+    HIPCHK(hipMemcpyAsync(pc.p, Pc, 3 * sizeof(double), hipMemcpyHostToDevice, s));
+    const size_t tiles = m_pad / kTileQ;
+    if (q_splits < 1) q_splits = 1;
+    if ((size_t)q_splits > tiles) q_splits = (int)tiles;
+    int ppl = env_int("ICP_AMD_PPL", 4);
+    if (ppl != 1 && ppl != 2 && ppl != 4) ppl = 4;
+    HIPCHK(keys.alloc((size_t)q_splits * n_pad * sizeof(double)));
+    HIPCHK(idxs.alloc((size_t)q_splits * n_pad * sizeof(uint32_t)));
+    HIPCHK(out.alloc(n_pad * sizeof(uint32_t)));
+    HIPCHK(part.alloc((n_pad / kChunk) * kCovW * sizeof(double)));
+    const int variant = search_variant == ICP_AMD_SEARCH_FMA ? kFma : kExact;
+    HIPCHK(search(s, variant, ppl, dP, n_pad, pc.as<double>(), dQ, m_pad, q_splits, keys.as<double>(), idxs.as<uint32_t>()));
+    HIPCHK(merge_cov(s, dP, n, n_pad, pc.as<double>(), dQ, m, q_splits, keys.as<double>(), idxs.as<uint32_t>(),
+                     out.as<uint32_t>(), part.as<double>()));
+    HIPCHK(hipMemcpyAsync(idx, out.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return ICP_AMD_OK;
+}
+
+extern "C" int icp_amd_cross_cov(const double *P, size_t n, const double Pc[3], const double *Qz, size_t m, const int32_t *idx,
+                                 double cov[9])
+{
+    if (!P || !Pc || !Qz || !idx || !cov) return fail(ICP_AMD_EINVAL, "icp_amd_cross_cov: NULL argument");
+    if (n == 0 || m == 0 || n > kMaxRows || m > kMaxRows) return fail(ICP_AMD_EINVAL, "icp_amd_cross_cov: bad sizes");
+    for (size_t i = 0; i < n; ++i)
+        if (idx[i] < 0 || (size_t)idx[i] >= m) return fail(ICP_AMD_EINVAL, "icp_amd_cross_cov: idx[%zu]=%d out of range", i, idx[i]);
+    RCCHK(require_device(env_int("ICP_AMD_DEVICE", 0)));
+    hipStream_t s = nullptr;
+    const size_t n_pad = round_up(n, kChunk), m_pad = round_up(m, kTileQ), chunks = n_pad / kChunk;
+    DevBuf pst, pstage, qst, qstage, pc, qc, di, part, rec;
+    Soa3 dP, dQ;
+    RCCHK(upload_soa(s, P, n, n_pad, 0.0, pst, pstage, dP));
+    RCCHK(upload_soa(s, Qz, m, m_pad, 0.0, qst, qstage, dQ));
+    HIPCHK(pc.alloc(3 * sizeof(double)));
+    HIPCHK(qc.alloc(3 * sizeof(double)));
+    HIPCHK(hipMemcpyAsync(pc.p, Pc, 3 * sizeof(double), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemsetAsync(qc.p, 0, 3 * sizeof(double), s));
+    HIPCHK(di.alloc(n * sizeof(uint32_t)));
+    HIPCHK(hipMemcpyAsync(di.p, idx, n * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+    HIPCHK(part.alloc(chunks * kCovW * sizeof(double)));
+    HIPCHK(rec.alloc(kSolveW * sizeof(double)));
+    HIPCHK(cov_from_idx(s, dP, n, pc.as<double>(), dQ, m, di.as<uint32_t>(), part.as<double>()));
+    HIPCHK(solve(s, part.as<double>(), chunks, pc.as<double>(), qc.as<double>(), (double)n, rec.as<double>()));
+    HIPCHK(hipMemcpyAsync(cov, rec.p, 9 * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return ICP_AMD_OK;
+}
+
+extern "C" int icp_amd_centroid(const double *A, size_t n, double out[3])
+{
+    if (!A || !out) return fail(ICP_AMD_EINVAL, "icp_amd_centroid: NULL argument");
+    if (n == 0) return fail(ICP_AMD_EINVAL, "icp_amd_centroid: empty cloud");
+    RCCHK(require_device(env_int("ICP_AMD_DEVICE", 0)));
+    hipStream_t s = nullptr;
+    const size_t chunks = (n + kChunk - 1) / kChunk;
+    DevBuf a, part, o;
+    HIPCHK(a.alloc(n * 3 * sizeof(double)));
+    HIPCHK(part.alloc(chunks * kCenW * sizeof(double)));
+    HIPCHK(o.alloc(3 * sizeof(double)));
+    HIPCHK(hipMemcpyAsync(a.p, A, n * 3 * sizeof(double), hipMemcpyHostToDevice, s));
+    HIPCHK(colsum_partials(s, a.as<double>(), Soa3{nullptr, nullptr, nullptr}, n, part.as<double>()));
+    HIPCHK(finalize_centroid(s, part.as<double>(), chunks, (double)n, o.as<double>()));
+    HIPCHK(hipMemcpyAsync(out, o.p, 3 * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return ICP_AMD_OK;
+}
+
+extern "C" int icp_amd_solve(const double cov[9], const double Pc[3], const double Qc[3], double R[9], double t[3], double S[3])
+{
+    if (!cov || !Pc || !Qc) return fail(ICP_AMD_EINVAL, "icp_amd_solve: NULL argument");
+    RCCHK(require_device(env_int("ICP_AMD_DEVICE", 0)));
+    hipStream_t s = nullptr;
+    DevBuf part, pc, qc, rec;
+    double h[kCovW] = {0};
+    memcpy(h, cov, 9 * sizeof(double));
+    HIPCHK(part.alloc(sizeof h));
+    HIPCHK(pc.alloc(3 * sizeof(double)));
+    HIPCHK(qc.alloc(3 * sizeof(double)));
+    HIPCHK(rec.alloc(kSolveW * sizeof(double)));
+    HIPCHK(hipMemcpyAsync(part.p, h, sizeof h, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(pc.p, Pc, 3 * sizeof(double), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(qc.p, Qc, 3 * sizeof(double), hipMemcpyHostToDevice, s));
+    HIPCHK(solve(s, part.as<double>(), 1, pc.as<double>(), qc.as<double>(), 1.0, rec.as<double>()));
+    double r[kSolveW];
+    HIPCHK(hipMemcpyAsync(r, rec.p, sizeof r, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (S) memcpy(S, r + 9, 3 * sizeof(double));
+    if (R) memcpy(R, r + 12, 9 * sizeof(double));
+    if (t) memcpy(t, r + 21, 3 * sizeof(double));
+    return ICP_AMD_OK;
+}
+
+extern "C" int icp_amd_apply(const double *P, size_t n, const double R[9], const double t[3], double *P_out)
+{
+    if (!P || !R || !t || !P_out) return fail(ICP_AMD_EINVAL, "icp_amd_apply: NULL argument");
+    if (n == 0) return fail(ICP_AMD_EINVAL, "icp_amd_apply: empty cloud");
+    RCCHK(require_device(env_int("ICP_AMD_DEVICE", 0)));
+    hipStream_t s = nullptr;
+    const size_t n_pad = round_up(n, kChunk);
+    DevBuf pst, pstage, rec, cen;
+    Soa3 dP;
+    RCCHK(upload_soa(s, P, n, n_pad, 0.0, pst, pstage, dP));
+    double h[kSolveW] = {0};
+    memcpy(h + 12, R, 9 * sizeof(double));
+    memcpy(h + 21, t, 3 * sizeof(double));
+    HIPCHK(rec.alloc(sizeof h));
+    HIPCHK(cen.alloc((n_pad / kChunk) * kCenW * sizeof(double)));
+    HIPCHK(hipMemcpyAsync(rec.p, h, sizeof h, hipMemcpyHostToDevice, s));
+    HIPCHK(apply(s, dP, n, rec.as<double>(), cen.as<double>()));
+    HIPCHK(soa_to_aos(s, dP, n, pstage.as<double>()));
+    HIPCHK(hipMemcpyAsync(P_out, pstage.p, n * 3 * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return ICP_AMD_OK;
+}
+
+// test hook (not in the public header): device sqrt(sqrt(x)) must be correctly rounded like the host's
+extern "C" int icp_amd_test_fourth_root(const double *d2, size_t n, double *key)
+{
+    if (!d2 || !key || n == 0) return fail(ICP_AMD_EINVAL, "icp_amd_test_fourth_root: bad argument");
+    RCCHK(require_device(env_int("ICP_AMD_DEVICE", 0)));
+    DevBuf a, b;
+    HIPCHK(a.alloc(n * sizeof(double)));
+    HIPCHK(b.alloc(n * sizeof(double)));
+    HIPCHK(hipMemcpy(a.p, d2, n * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(fourth_root(nullptr, a.as<double>(), n, b.as<double>()));
+    HIPCHK(hipMemcpy(key, b.p, n * sizeof(double), hipMemcpyDeviceToHost));
+    return ICP_AMD_OK;
+}

@@ -1,0 +1,59 @@
+// GPUICP -- command-line drop-in for the reference's GPU executable (reference src/gpu/main.cu:58-81):
+//   ./GPUICP file1 file2 nbiters method={-loop|-batch|-shared|-shared-loop}
+// Same arguments, same stdout line, same output file; built on the C ABI of libicp_amd.so only.
+// Argument / shape errors throw an uncaught std::runtime_error like the reference's runtime_assert
+// (include/error.hpp:6-15); device errors print and exit(EXIT_FAILURE) like cudaCheckError
+// (include/error.cuh:3-9).
+#include <cstdio>
+#include <cstdlib>
+#include <iostream>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/icp_amd.h"
+
+static void runtime_assert(bool cond, const std::string &msg)
+{
+    if (!cond) throw std::runtime_error(msg);
+}
+
+static std::vector<double> load(const char *path, size_t &rows, size_t &cols)
+{
+    double *a = nullptr;
+    const int rc = icp_amd_read_csv(path, &a, &rows, &cols, nullptr, 0);
+    runtime_assert(rc == ICP_AMD_OK, icp_amd_last_error());
+    std::vector<double> v(a, a + rows * cols);
+    icp_amd_free(a);
+    return v;
+}
+
+int main(int argc, char **argv)
+{
+    runtime_assert(argc == 5, "Usage: ./GPUICP file1 file2 nbiters method={-loop|-batch|-shared|-shared-loop}");
+    size_t Pl, Pc, Ql, Qc;
+    std::vector<double> P = load(argv[1], Pl, Pc);
+    std::vector<double> Q = load(argv[2], Ql, Qc);
+    const unsigned nbiters = (unsigned)std::stoi(argv[3]);
+    const std::string method{argv[4]};
+    runtime_assert(method == "-batch" || method == "-loop" || method == "-shared" || method == "-shared-loop",
+                   "Invalid method, must be: -shared|-loop|-shared-loop|-batch");
+    const int m = method == "-batch" ? ICP_AMD_METHOD_BATCH
+                  : method == "-loop" ? ICP_AMD_METHOD_LOOP
+                  : method == "-shared" ? ICP_AMD_METHOD_SHARED : ICP_AMD_METHOD_SHARED_LOOP;
+    // the reference hard-wires 3 columns in every kernel; other shapes end in a broadcasting error
+    runtime_assert(Pc == 3 && Qc == 3, "element_wise_reduce requires arrays to be broadcastable");
+    runtime_assert(Pl > 0 && Ql > 0, "empty point cloud");
+    std::vector<double> P_res(Pl * 3);
+    const int rc = icp_amd_run(P.data(), Pl, Q.data(), Ql, nbiters, m, P_res.data(), nullptr);
+    if (rc == ICP_AMD_EINVAL) throw std::runtime_error(icp_amd_last_error());
+    if (rc != ICP_AMD_OK) {
+        printf("HIP failure: %s\n", icp_amd_last_error());
+        exit(EXIT_FAILURE);
+    }
+    // Q.euclidianDistance(P_res) needs equal shapes in the reference (it throws otherwise)
+    runtime_assert(Pl == Ql, "element_wise_reduce requires arrays to be broadcastable");
+    std::cout << "Squared actual mean diff: " << icp_amd_euclidian_distance(Q.data(), P_res.data(), Ql, 3) << std::endl;
+    runtime_assert(icp_amd_write_cloud("point_cloud_result", P_res.data(), Pl, 3) == ICP_AMD_OK, "could not write point_cloud_result");
+    return 0;
+}

@@ -1,0 +1,57 @@
+// icp_amd/csrc/kernels.h -- internal: launchers of the gfx950 kernels (kernels.hip), used by engine.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+namespace icpk {
+
+// Geometry shared by every kernel.
+constexpr int kWG      = 256;    // threads per workgroup (4 wave64)
+constexpr int kChunk   = 1024;   // source rows per reduction leaf / per cov-apply workgroup
+constexpr int kTileQ   = 1024;   // target points per LDS tile; Q arrays are padded to a multiple with +inf
+constexpr int kCovW    = 12;     // doubles per cov partial: 9 cov sums, sum d^2, 2 spare
+constexpr int kCenW    = 3;      // doubles per centroid partial
+
+enum SearchVariant { kExact = 1, kFma = 2 };
+
+struct Soa3 {            // device SoA view of a cloud
+    double *x, *y, *z;
+};
+
+// Sum of each coordinate over 1024-row chunks: partial[chunk][3] (fixed reduction order).
+// src is row-major AoS (n x 3) when aos != nullptr, else the SoA view.
+hipError_t colsum_partials(hipStream_t s, const double *aos, Soa3 soa, size_t n, double *partial);
+// out[k] = (sum over `count` partials in index order)[k] / denom     (k < 3)
+hipError_t finalize_centroid(hipStream_t s, const double *partial, size_t count, double denom, double *out3);
+// AoS -> SoA, padded rows [n, n_pad) set to `pad`.  If c3 != nullptr subtracts c3[k] (the centring of Q).
+hipError_t aos_to_soa(hipStream_t s, const double *aos, size_t n, size_t n_pad, const double *c3, double pad, Soa3 out);
+hipError_t soa_to_aos(hipStream_t s, Soa3 in, size_t n, double *aos);
+
+// Brute-force nearest neighbour: for source row i (centred on the fly with pc) and target split y,
+// (key, idx) of the lexicographically smallest (sqrt(sqrt(d^2)), j) over the split's target range.
+// out_key / out_idx are [q_splits][n_pad].  n_pad multiple of 256*ppl, m_pad multiple of kTileQ.
+hipError_t search(hipStream_t s, int variant, int ppl, Soa3 P, size_t n_pad, const double *pc,
+                  Soa3 Qz, size_t m_pad, int q_splits, double *out_key, uint32_t *out_idx);
+
+// Merge the splits (lowest index among equal keys), write idx[n], and reduce q (x) p per 1024-row chunk
+// into partial[chunk][12].
+hipError_t merge_cov(hipStream_t s, Soa3 P, size_t n, size_t n_pad, const double *pc, Soa3 Qz, size_t m,
+                     int q_splits, const double *keys, const uint32_t *idxs, uint32_t *idx_out,
+                     double *partial);
+// cov partials from a given idx (stage-level entry).
+hipError_t cov_from_idx(hipStream_t s, Soa3 P, size_t n, const double *pc, Soa3 Qz, size_t m, const uint32_t *idx,
+                        double *partial);
+
+// Sum `count` cov partials in index order, 3x3 SVD, R = U V^T, t = Qc - Pc R^T.
+// out: [0..8] cov, [9..11] S, [12..20] R, [21..23] t, [24] rms, [25..27] Pc copy  (28 doubles)
+constexpr int kSolveW = 28;
+hipError_t solve(hipStream_t s, const double *partial, size_t count, const double *pc, const double *qc,
+                 double n_global, double *out);
+// P <- P R^T + t (R, t read from the solve record) and per-chunk sums of the new P.
+hipError_t apply(hipStream_t s, Soa3 P, size_t n, const double *solve_rec, double *cen_partial);
+
+// test hook: key[i] = sqrt(sqrt(d2[i])) computed on the device
+hipError_t fourth_root(hipStream_t s, const double *d2, size_t n, double *key);
+
+}  // namespace icpk

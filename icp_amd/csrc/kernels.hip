@@ -1,0 +1,573 @@
+// icp_amd/csrc/kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the ICP hot path.
+//
+// Built with -ffp-contract=off: the reference CPU path (the parity oracle) evaluates every product and
+// sum with its own rounding (x86-64, no FMA), and exact ties between candidates only stay ties if the
+// device does the same.  Fusion is used only where it is asked for explicitly (__builtin_fma in the
+// pre-filter of the search kernel, whose candidates are always re-evaluated un-fused).
+//
+// Data layout: clouds live in HBM as SoA (x[], y[], z[]), fp64, source rows padded to a multiple of 1024
+// (pad rows are finite and never counted), target rows centred once and padded with +inf to a multiple
+// of the LDS tile (a pad target has d^2 = +inf and can never win).
+//
+// Determinism: no floating-point atomics; every reduction is a fixed-shape tree inside a 1024-row chunk
+// followed by an in-index-order sum over chunks, so results do not depend on the grid, on the number of
+// target splits, or on how many GPUs share the source rows.
+#include "kernels.h"
+
+#include <math.h>
+
+namespace icpk {
+
+// ------------------------------------------------------------------------------------------------
+// reductions
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// Sum NV per-thread values over the 256-thread workgroup; thread k < NV returns the total of value k.
+// smem holds 4*NV doubles.  Order: butterfly inside each wave, then waves 0..3 in order.
+template <int NV>
+__device__ __forceinline__ double block_sum(double (&v)[NV], double *smem)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        double r = wave_sum(v[k]);
+        if (lane == 0) smem[w * NV + k] = r;
+    }
+    __syncthreads();
+    double tot = 0.0;
+    if (threadIdx.x < NV) {
+        const int k = threadIdx.x;
+        tot = ((smem[0 * NV + k] + smem[1 * NV + k]) + smem[2 * NV + k]) + smem[3 * NV + k];
+    }
+    return tot;
+}
+
+// In-index-order sum of `count` partial records of W doubles; thread k < W ends with the total of column k.
+// Records are staged through LDS in batches so that the dependent add chain never waits on HBM.
+template <int W>
+__device__ __forceinline__ double ordered_sum(const double *__restrict__ partial, size_t count, double *stage /*[kStage]*/)
+{
+    constexpr int kStageRecs = 256;
+    double acc = 0.0;
+    for (size_t r0 = 0; r0 < count; r0 += kStageRecs) {
+        const int recs = (int)((count - r0 < (size_t)kStageRecs) ? (count - r0) : (size_t)kStageRecs);
+        __syncthreads();
+        for (int k = threadIdx.x; k < recs * W; k += kWG) stage[k] = partial[r0 * W + k];
+        __syncthreads();
+        if (threadIdx.x < W)
+            for (int r = 0; r < recs; ++r) acc += stage[r * W + threadIdx.x];
+    }
+    return acc;
+}
+
+__global__ __launch_bounds__(kWG) void colsum_partials_kernel(const double *__restrict__ aos, const double *__restrict__ x,
+                                                              const double *__restrict__ y, const double *__restrict__ z,
+                                                              size_t n, double *__restrict__ partial)
+{
+    __shared__ double smem[4 * 3];
+    double acc[3] = {0.0, 0.0, 0.0};
+    const size_t base = (size_t)blockIdx.x * kChunk + threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < kChunk / kWG; ++k) {
+        const size_t i = base + (size_t)k * kWG;
+        if (i < n) {
+            if (aos) {
+                acc[0] += aos[i * 3 + 0];
+                acc[1] += aos[i * 3 + 1];
+                acc[2] += aos[i * 3 + 2];
+            } else {
+                acc[0] += x[i];
+                acc[1] += y[i];
+                acc[2] += z[i];
+            }
+        }
+    }
+    const double tot = block_sum<3>(acc, smem);
+    if (threadIdx.x < 3) partial[(size_t)blockIdx.x * kCenW + threadIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(kWG) void finalize_centroid_kernel(const double *__restrict__ partial, size_t count, double denom,
+                                                                double *__restrict__ out3)
+{
+    __shared__ double stage[256 * kCenW];
+    const double acc = ordered_sum<kCenW>(partial, count, stage);
+    if (threadIdx.x < 3) out3[threadIdx.x] = acc / denom;
+}
+
+__global__ __launch_bounds__(kWG) void aos_to_soa_kernel(const double *__restrict__ aos, size_t n, size_t n_pad,
+                                                         const double *__restrict__ c3, double pad, double *__restrict__ x,
+                                                         double *__restrict__ y, double *__restrict__ z)
+{
+    const size_t i = (size_t)blockIdx.x * kWG + threadIdx.x;
+    if (i >= n_pad) return;
+    double vx = pad, vy = pad, vz = pad;
+    if (i < n) {
+        vx = aos[i * 3 + 0];
+        vy = aos[i * 3 + 1];
+        vz = aos[i * 3 + 2];
+        if (c3) {  // Q -= Q_center (reference src/cpu/icp.cpp:198)
+            vx = vx - c3[0];
+            vy = vy - c3[1];
+            vz = vz - c3[2];
+        }
+    }
+    x[i] = vx;
+    y[i] = vy;
+    z[i] = vz;
+}
+
+__global__ __launch_bounds__(kWG) void soa_to_aos_kernel(const double *__restrict__ x, const double *__restrict__ y,
+                                                         const double *__restrict__ z, size_t n, double *__restrict__ aos)
+{
+    const size_t i = (size_t)blockIdx.x * kWG + threadIdx.x;
+    if (i >= n) return;
+    aos[i * 3 + 0] = x[i];
+    aos[i * 3 + 1] = y[i];
+    aos[i * 3 + 2] = z[i];
+}
+
+// ------------------------------------------------------------------------------------------------
+// correspondence search
+// ------------------------------------------------------------------------------------------------
+// The oracle's squared distance (reference src/libalg/alg.cpp:22-30 with squared_norm_2/add/add,
+// basic_operations.cpp:5-13): tmp = ((0 + dx*dx) + dy*dy) + dz*dz, r = 0 + tmp; every op rounded.
+__device__ __forceinline__ double d2_exact(double ax, double ay, double az, double qx, double qy, double qz)
+{
+    const double dx = ax - qx, dy = ay - qy, dz = az - qz;
+    return (dx * dx + dy * dy) + dz * dz;
+}
+// Same differences, products fused into the sums: within (1+u)^6 of d2_exact; pre-filter only.
+__device__ __forceinline__ double d2_fused(double ax, double ay, double az, double qx, double qy, double qz)
+{
+    const double dx = ax - qx, dy = ay - qy, dz = az - qz;
+    return __builtin_fma(dz, dz, __builtin_fma(dy, dy, dx * dx));
+}
+// The oracle's comparison key (src/cpu/icp.cpp:83 on top of CPUMatrix.cpp:291-295): sqrt applied twice.
+__device__ __forceinline__ double key_of(double d2) { return sqrt(sqrt(d2)); }
+
+constexpr int kCB = 8;  // targets per unrolled block between two event checks
+
+// Slow path, entered by the lanes whose running minimum dropped inside the last block of kCB targets:
+// re-evaluates the block un-fused, in target order, and updates the lexicographic best (key, index).
+// Invariant on exit: bd = smallest exact d^2 seen so far, and every target that can still beat
+// (bk, bj) has d^2 < bd (key is a monotone function of d^2, targets arrive in ascending index order).
+__device__ __forceinline__ void rescan_block(double ax, double ay, double az, const double *sx, const double *sy,
+                                             const double *sz, int j0, unsigned jglobal, double &bd, double &bk, uint32_t &bj)
+{
+    for (int u = 0; u < kCB; ++u) {
+        const double d = d2_exact(ax, ay, az, sx[j0 + u], sy[j0 + u], sz[j0 + u]);
+        if (d < bd) {
+            bd = d;
+            const double key = key_of(d);
+            const uint32_t j = jglobal + (unsigned)u;
+            if (key < bk || (key == bk && j < bj)) {
+                bk = key;
+                bj = j;
+            }
+        }
+    }
+}
+
+// grid = (n_pad / (256*PPL), q_splits).  Every lane owns PPL source points (kept in registers, centred
+// on load); the workgroup streams its target range through a 24 KB SoA LDS tile, and all lanes of a wave
+// read the same target (LDS broadcast), so the inner loop is pure fp64 VALU: 8 ops per pair for the
+// distance (6 in the fused pre-filter) + 1 v_min_f64.  Indices are not tracked in the fast path at all.
+template <int PPL, int MODE>
+__global__ __launch_bounds__(kWG) void search_kernel(const double *__restrict__ px, const double *__restrict__ py,
+                                                     const double *__restrict__ pz, const double *__restrict__ pc,
+                                                     const double *__restrict__ qx, const double *__restrict__ qy,
+                                                     const double *__restrict__ qz, unsigned n_pad, unsigned m_pad,
+                                                     unsigned q_per_split, double *__restrict__ out_key,
+                                                     uint32_t *__restrict__ out_idx)
+{
+    __shared__ double sq[3][kTileQ];
+    const unsigned tid = threadIdx.x;
+    const unsigned base = blockIdx.x * (kWG * PPL) + tid;
+    const double c0 = pc[0], c1 = pc[1], c2 = pc[2];
+
+    double ax[PPL], ay[PPL], az[PPL];  // centred source points: P = P_copy - P_center (src/cpu/icp.cpp:208)
+    double m[PPL];                     // running minimum in filter space, starts each block at thr
+    double thr[PPL];                   // filter-space image of bd
+    double bd[PPL], bk[PPL];
+    uint32_t bj[PPL];
+#pragma unroll
+    for (int s = 0; s < PPL; ++s) {
+        ax[s] = px[base + s * kWG] - c0;
+        ay[s] = py[base + s * kWG] - c1;
+        az[s] = pz[base + s * kWG] - c2;
+        bd[s] = INFINITY;  // oracle: min_dist = DBL_MAX on the key, i.e. any finite d^2 is accepted
+        bk[s] = INFINITY;
+        bj[s] = 0xFFFFFFFFu;
+        thr[s] = INFINITY;
+        m[s] = INFINITY;
+    }
+
+    const unsigned q0 = blockIdx.y * q_per_split;
+    const unsigned q1 = (q0 + q_per_split < m_pad) ? (q0 + q_per_split) : m_pad;
+    for (unsigned t0 = q0; t0 < q1; t0 += kTileQ) {
+        __syncthreads();
+        for (int k = tid; k < kTileQ; k += kWG) {
+            sq[0][k] = qx[t0 + k];
+            sq[1][k] = qy[t0 + k];
+            sq[2][k] = qz[t0 + k];
+        }
+        __syncthreads();
+        for (int j0 = 0; j0 < kTileQ; j0 += kCB) {
+#pragma unroll
+            for (int u = 0; u < kCB; ++u) {
+                const double tx = sq[0][j0 + u], ty = sq[1][j0 + u], tz = sq[2][j0 + u];
+#pragma unroll
+                for (int s = 0; s < PPL; ++s) {
+                    const double d = (MODE == kFma) ? d2_fused(ax[s], ay[s], az[s], tx, ty, tz)
+                                                    : d2_exact(ax[s], ay[s], az[s], tx, ty, tz);
+                    m[s] = __builtin_fmin(m[s], d);
+                }
+            }
+            bool ev = false;
+#pragma unroll
+            for (int s = 0; s < PPL; ++s) ev |= (m[s] < thr[s]);
+            if (ev) {
+#pragma unroll
+                for (int s = 0; s < PPL; ++s) {
+                    if (m[s] < thr[s]) {
+                        rescan_block(ax[s], ay[s], az[s], sq[0], sq[1], sq[2], j0, t0 + (unsigned)j0, bd[s], bk[s], bj[s]);
+                        // fused and un-fused d^2 agree within (1+u)^6: any target with exact d^2 < bd has a
+                        // fused d^2 below bd*(1+2^-49) (+ a subnormal-range guard)
+                        thr[s] = (MODE == kFma) ? __builtin_fma(bd[s], 1.0 + 0x1p-49, 1e-300) : bd[s];
+                        m[s] = thr[s];
+                    }
+                }
+            }
+        }
+    }
+    const size_t o = (size_t)blockIdx.y * n_pad + base;
+#pragma unroll
+    for (int s = 0; s < PPL; ++s) {
+        out_key[o + s * kWG] = bk[s];
+        out_idx[o + s * kWG] = bj[s];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// merge of the target splits + cross-covariance partials
+// ------------------------------------------------------------------------------------------------
+// cov[a][b] = sum_i Qz[idx[i]][a] * Pz[i][b]  (reference src/cpu/icp.cpp:108-131: q^T . p per point, each
+// product rounded once, summed).  MERGE: idx comes from the per-split (key, idx) records; otherwise from idx_in.
+template <bool MERGE>
+__global__ __launch_bounds__(kWG) void cov_kernel(const double *__restrict__ px, const double *__restrict__ py,
+                                                  const double *__restrict__ pz, size_t n, size_t n_pad,
+                                                  const double *__restrict__ pc, const double *__restrict__ qx,
+                                                  const double *__restrict__ qy, const double *__restrict__ qz, size_t m,
+                                                  int q_splits, const double *__restrict__ keys,
+                                                  const uint32_t *__restrict__ idxs, const uint32_t *__restrict__ idx_in,
+                                                  uint32_t *__restrict__ idx_out, double *__restrict__ partial)
+{
+    __shared__ double smem[4 * kCovW];
+    const double c0 = pc[0], c1 = pc[1], c2 = pc[2];
+    double acc[kCovW];
+#pragma unroll
+    for (int k = 0; k < kCovW; ++k) acc[k] = 0.0;
+    const size_t base = (size_t)blockIdx.x * kChunk + threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < kChunk / kWG; ++k) {
+        const size_t i = base + (size_t)k * kWG;
+        if (i < n) {
+            uint32_t j;
+            if (MERGE) {
+                double bk = keys[i];
+                j = idxs[i];
+                for (int y = 1; y < q_splits; ++y) {  // ascending target ranges: strict < keeps the lowest index
+                    const double ky = keys[(size_t)y * n_pad + i];
+                    if (ky < bk) {
+                        bk = ky;
+                        j = idxs[(size_t)y * n_pad + i];
+                    }
+                }
+                idx_out[i] = j;
+            } else {
+                j = idx_in[i];
+            }
+            if (j < m) {
+                const double p0 = px[i] - c0, p1 = py[i] - c1, p2 = pz[i] - c2;
+                const double q0 = qx[j], q1 = qy[j], q2 = qz[j];
+                acc[0] += q0 * p0; acc[1] += q0 * p1; acc[2] += q0 * p2;
+                acc[3] += q1 * p0; acc[4] += q1 * p1; acc[5] += q1 * p2;
+                acc[6] += q2 * p0; acc[7] += q2 * p1; acc[8] += q2 * p2;
+                acc[9] += d2_exact(p0, p1, p2, q0, q1, q2);
+            }
+        }
+    }
+    const double tot = block_sum<kCovW>(acc, smem);
+    if (threadIdx.x < kCovW) partial[(size_t)blockIdx.x * kCovW + threadIdx.x] = tot;
+}
+
+// ------------------------------------------------------------------------------------------------
+// 3x3 solve
+// ------------------------------------------------------------------------------------------------
+// One-sided (Hestenes) Jacobi SVD of the row-major 3x3 A: A V = U diag(S).  Replaces cusolverDnDgesvd
+// (reference src/libgpualg/svd.cu:19-115) / LAPACK dgesvd_ (src/libalg/svd.cpp:36-73).  Only R = U V^T is
+// consumed by the hot path; it is the orthogonal polar factor of A and does not depend on factor signs.
+// Directions of singular values at roundoff level (<= 1e-13 S[0]) are completed so that det(U) = det(V).
+__device__ void svd3(const double *A, double *U, double *S, double *VT)
+{
+    double a[9], v[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    for (int k = 0; k < 9; ++k) a[k] = A[k];
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        bool rotated = false;
+        for (int k = 0; k < 3; ++k) {
+            const int p = (k == 2) ? 1 : 0, q = (k == 0) ? 1 : 2;
+            double alpha = 0, beta = 0, gamma = 0;
+            for (int i = 0; i < 3; ++i) {
+                alpha += a[i * 3 + p] * a[i * 3 + p];
+                beta += a[i * 3 + q] * a[i * 3 + q];
+                gamma += a[i * 3 + p] * a[i * 3 + q];
+            }
+            if (gamma == 0.0 || fabs(gamma) <= 1e-17 * sqrt(alpha * beta)) continue;
+            rotated = true;
+            const double zeta = (beta - alpha) / (2.0 * gamma);
+            const double tt = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+            const double c = 1.0 / sqrt(1.0 + tt * tt), s = c * tt;
+            for (int i = 0; i < 3; ++i) {
+                double x = a[i * 3 + p], y = a[i * 3 + q];
+                a[i * 3 + p] = c * x - s * y;
+                a[i * 3 + q] = s * x + c * y;
+                x = v[i * 3 + p];
+                y = v[i * 3 + q];
+                v[i * 3 + p] = c * x - s * y;
+                v[i * 3 + q] = s * x + c * y;
+            }
+        }
+        if (!rotated) break;
+    }
+    double sg[3];
+    int ord[3] = {0, 1, 2};
+    for (int j = 0; j < 3; ++j) sg[j] = sqrt(a[j] * a[j] + a[3 + j] * a[3 + j] + a[6 + j] * a[6 + j]);
+    for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 2 - i; ++j)
+            if (sg[ord[j]] < sg[ord[j + 1]]) {
+                const int t = ord[j];
+                ord[j] = ord[j + 1];
+                ord[j + 1] = t;
+            }
+    double u[9], vv[9];
+    const double tol = 1e-13 * sg[ord[0]];
+    int rank = 0;
+    for (int j = 0; j < 3; ++j) {
+        const int c = ord[j];
+        S[j] = sg[c];
+        for (int i = 0; i < 3; ++i) vv[i * 3 + j] = v[i * 3 + c];
+        const bool ok = sg[c] > 0.0 && sg[c] > tol && rank == j;
+        for (int i = 0; i < 3; ++i) u[i * 3 + j] = ok ? a[i * 3 + c] / sg[c] : 0.0;
+        if (ok) rank = j + 1;
+    }
+    const double detv = vv[0] * (vv[4] * vv[8] - vv[5] * vv[7]) - vv[1] * (vv[3] * vv[8] - vv[5] * vv[6]) +
+                        vv[2] * (vv[3] * vv[7] - vv[4] * vv[6]);
+    if (rank == 0) {
+        for (int k = 0; k < 9; ++k) u[k] = vv[k];
+    } else {
+        if (rank == 1) {  // any unit vector orthogonal to u0
+            int mm = 0;
+            if (fabs(u[3]) < fabs(u[mm * 3])) mm = 1;
+            if (fabs(u[6]) < fabs(u[mm * 3])) mm = 2;
+            double e[3] = {0, 0, 0};
+            e[mm] = 1.0;
+            u[1] = u[3] * e[2] - u[6] * e[1];
+            u[4] = u[6] * e[0] - u[0] * e[2];
+            u[7] = u[0] * e[1] - u[3] * e[0];
+        }
+        const double d01 = u[0] * u[1] + u[3] * u[4] + u[6] * u[7];
+        for (int i = 0; i < 3; ++i) u[i * 3 + 1] -= d01 * u[i * 3];
+        const double n1 = sqrt(u[1] * u[1] + u[4] * u[4] + u[7] * u[7]);
+        for (int i = 0; i < 3; ++i) u[i * 3 + 1] /= n1;
+        const double w[3] = {u[3] * u[7] - u[6] * u[4], u[6] * u[1] - u[0] * u[7], u[0] * u[4] - u[3] * u[1]};
+        double s3 = detv < 0 ? -1.0 : 1.0;
+        if (rank == 3) s3 = (w[0] * u[2] + w[1] * u[5] + w[2] * u[8]) < 0 ? -1.0 : 1.0;
+        for (int i = 0; i < 3; ++i) u[i * 3 + 2] = s3 * w[i];
+    }
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            U[i * 3 + j] = u[i * 3 + j];
+            VT[i * 3 + j] = vv[j * 3 + i];
+        }
+}
+
+__global__ __launch_bounds__(kWG) void solve_kernel(const double *__restrict__ partial, size_t count,
+                                                    const double *__restrict__ pc, const double *__restrict__ qc,
+                                                    double n_global, double *__restrict__ out)
+{
+    __shared__ double stage[256 * kCovW];
+    __shared__ double tot[kCovW];
+    const double acc = ordered_sum<kCovW>(partial, count, stage);
+    if (threadIdx.x < kCovW) tot[threadIdx.x] = acc;
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    double cov[9], U[9], S[3], VT[9], R[9], t[3];
+    for (int k = 0; k < 9; ++k) cov[k] = tot[k];
+    svd3(cov, U, S, VT);
+    // R = U.dot(V_T) (src/cpu/icp.cpp:221); dot_product sums tmp += a*b in m order (src/libalg/alg.cpp:91-101)
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            double tmp = 0.0;
+            for (int mm = 0; mm < 3; ++mm) tmp += U[i * 3 + mm] * VT[mm * 3 + j];
+            R[i * 3 + j] = tmp;
+        }
+    // t = Q_center - P_center.dot(R.transpose()) (src/cpu/icp.cpp:223)
+    for (int j = 0; j < 3; ++j) {
+        double tmp = 0.0;
+        for (int mm = 0; mm < 3; ++mm) tmp += pc[mm] * R[j * 3 + mm];
+        t[j] = qc[j] - tmp;
+    }
+    for (int k = 0; k < 9; ++k) out[k] = cov[k];
+    for (int k = 0; k < 3; ++k) out[9 + k] = S[k];
+    for (int k = 0; k < 9; ++k) out[12 + k] = R[k];
+    for (int k = 0; k < 3; ++k) out[21 + k] = t[k];
+    out[24] = sqrt(tot[9] / n_global);
+    for (int k = 0; k < 3; ++k) out[25 + k] = pc[k];
+}
+
+// ------------------------------------------------------------------------------------------------
+// transform apply + centroid partials of the new cloud
+// ------------------------------------------------------------------------------------------------
+// P_copy = P_copy.dot(R.transpose()) + t (src/cpu/icp.cpp:225): per row and output column j,
+// ((0 + x R[j][0]) + y R[j][1]) + z R[j][2], then + t[j]; un-fused.
+__global__ __launch_bounds__(kWG) void apply_kernel(double *__restrict__ px, double *__restrict__ py, double *__restrict__ pz,
+                                                    size_t n, const double *__restrict__ rec, double *__restrict__ cen_partial)
+{
+    __shared__ double smem[4 * 3];
+    const double *R = rec + 12, *t = rec + 21;
+    const double r00 = R[0], r01 = R[1], r02 = R[2], r10 = R[3], r11 = R[4], r12 = R[5], r20 = R[6], r21 = R[7], r22 = R[8];
+    const double t0 = t[0], t1 = t[1], t2 = t[2];
+    double acc[3] = {0.0, 0.0, 0.0};
+    const size_t base = (size_t)blockIdx.x * kChunk + threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < kChunk / kWG; ++k) {
+        const size_t i = base + (size_t)k * kWG;
+        if (i < n) {
+            const double x = px[i], y = py[i], z = pz[i];
+            const double nx = ((x * r00 + y * r01) + z * r02) + t0;
+            const double ny = ((x * r10 + y * r11) + z * r12) + t1;
+            const double nz = ((x * r20 + y * r21) + z * r22) + t2;
+            px[i] = nx;
+            py[i] = ny;
+            pz[i] = nz;
+            acc[0] += nx;
+            acc[1] += ny;
+            acc[2] += nz;
+        }
+    }
+    const double tot = block_sum<3>(acc, smem);
+    if (threadIdx.x < 3) cen_partial[(size_t)blockIdx.x * kCenW + threadIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(kWG) void fourth_root_kernel(const double *__restrict__ d2, size_t n, double *__restrict__ key)
+{
+    const size_t i = (size_t)blockIdx.x * kWG + threadIdx.x;
+    if (i < n) key[i] = key_of(d2[i]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// launchers (shapes are validated by the engine before any launch)
+// ------------------------------------------------------------------------------------------------
+static inline unsigned blocks_for(size_t n, size_t per) { return (unsigned)((n + per - 1) / per); }
+
+hipError_t colsum_partials(hipStream_t s, const double *aos, Soa3 soa, size_t n, double *partial)
+{
+    if (n == 0) return hipSuccess;
+    colsum_partials_kernel<<<blocks_for(n, kChunk), kWG, 0, s>>>(aos, soa.x, soa.y, soa.z, n, partial);
+    return hipGetLastError();
+}
+
+hipError_t finalize_centroid(hipStream_t s, const double *partial, size_t count, double denom, double *out3)
+{
+    finalize_centroid_kernel<<<1, kWG, 0, s>>>(partial, count, denom, out3);
+    return hipGetLastError();
+}
+
+hipError_t aos_to_soa(hipStream_t s, const double *aos, size_t n, size_t n_pad, const double *c3, double pad, Soa3 out)
+{
+    if (n_pad == 0) return hipSuccess;
+    aos_to_soa_kernel<<<blocks_for(n_pad, kWG), kWG, 0, s>>>(aos, n, n_pad, c3, pad, out.x, out.y, out.z);
+    return hipGetLastError();
+}
+
+hipError_t soa_to_aos(hipStream_t s, Soa3 in, size_t n, double *aos)
+{
+    if (n == 0) return hipSuccess;
+    soa_to_aos_kernel<<<blocks_for(n, kWG), kWG, 0, s>>>(in.x, in.y, in.z, n, aos);
+    return hipGetLastError();
+}
+
+template <int PPL>
+static hipError_t search_ppl(hipStream_t s, int variant, Soa3 P, size_t n_pad, const double *pc, Soa3 Qz, size_t m_pad,
+                             int q_splits, double *out_key, uint32_t *out_idx)
+{
+    const size_t tiles = m_pad / kTileQ;
+    const unsigned q_per_split = (unsigned)(((tiles + q_splits - 1) / q_splits) * kTileQ);
+    dim3 grid((unsigned)(n_pad / (kWG * PPL)), (unsigned)q_splits);
+    if (variant == kFma)
+        search_kernel<PPL, kFma><<<grid, kWG, 0, s>>>(P.x, P.y, P.z, pc, Qz.x, Qz.y, Qz.z, (unsigned)n_pad, (unsigned)m_pad,
+                                                      q_per_split, out_key, out_idx);
+    else
+        search_kernel<PPL, kExact><<<grid, kWG, 0, s>>>(P.x, P.y, P.z, pc, Qz.x, Qz.y, Qz.z, (unsigned)n_pad,
+                                                        (unsigned)m_pad, q_per_split, out_key, out_idx);
+    return hipGetLastError();
+}
+
+hipError_t search(hipStream_t s, int variant, int ppl, Soa3 P, size_t n_pad, const double *pc, Soa3 Qz, size_t m_pad,
+                  int q_splits, double *out_key, uint32_t *out_idx)
+{
+    if (n_pad == 0 || m_pad == 0 || n_pad % kChunk || m_pad % kTileQ || q_splits < 1) return hipErrorInvalidValue;
+    switch (ppl) {
+    case 1: return search_ppl<1>(s, variant, P, n_pad, pc, Qz, m_pad, q_splits, out_key, out_idx);
+    case 2: return search_ppl<2>(s, variant, P, n_pad, pc, Qz, m_pad, q_splits, out_key, out_idx);
+    case 4: return search_ppl<4>(s, variant, P, n_pad, pc, Qz, m_pad, q_splits, out_key, out_idx);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t merge_cov(hipStream_t s, Soa3 P, size_t n, size_t n_pad, const double *pc, Soa3 Qz, size_t m, int q_splits,
+                     const double *keys, const uint32_t *idxs, uint32_t *idx_out, double *partial)
+{
+    if (n == 0) return hipSuccess;
+    cov_kernel<true><<<blocks_for(n, kChunk), kWG, 0, s>>>(P.x, P.y, P.z, n, n_pad, pc, Qz.x, Qz.y, Qz.z, m, q_splits, keys,
+                                                           idxs, nullptr, idx_out, partial);
+    return hipGetLastError();
+}
+
+hipError_t cov_from_idx(hipStream_t s, Soa3 P, size_t n, const double *pc, Soa3 Qz, size_t m, const uint32_t *idx,
+                        double *partial)
+{
+    if (n == 0) return hipSuccess;
+    cov_kernel<false><<<blocks_for(n, kChunk), kWG, 0, s>>>(P.x, P.y, P.z, n, 0, pc, Qz.x, Qz.y, Qz.z, m, 1, nullptr, nullptr,
+                                                            idx, nullptr, partial);
+    return hipGetLastError();
+}
+
+hipError_t solve(hipStream_t s, const double *partial, size_t count, const double *pc, const double *qc, double n_global,
+                 double *out)
+{
+    solve_kernel<<<1, kWG, 0, s>>>(partial, count, pc, qc, n_global, out);
+    return hipGetLastError();
+}
+
+hipError_t apply(hipStream_t s, Soa3 P, size_t n, const double *solve_rec, double *cen_partial)
+{
+    if (n == 0) return hipSuccess;
+    apply_kernel<<<blocks_for(n, kChunk), kWG, 0, s>>>(P.x, P.y, P.z, n, solve_rec, cen_partial);
+    return hipGetLastError();
+}
+
+hipError_t fourth_root(hipStream_t s, const double *d2, size_t n, double *key)
+{
+    if (n == 0) return hipSuccess;
+    fourth_root_kernel<<<blocks_for(n, kWG), kWG, 0, s>>>(d2, n, key);
+    return hipGetLastError();
+}
+
+}  // namespace icpk

@@ -1,0 +1,152 @@
+/* include/icp_amd.h -- C ABI of the MI355X-native ICP engine (libicp_amd.so).
+ *
+ * Drop-in boundary for the GPU path of FanatoniQ/ICP.  The reference has no FFI: its GPU executable calls
+ * two C++ functions (reference include/gpu/icp.cuh:38-39) that in turn call the kernel wrappers of
+ * libgpuicp / libgpualg.  This header replaces that seam with plain-C entry points (pointers + sizes, no
+ * C++ or torch types): the whole loop (icp_amd_run), a persistent device-resident engine that can be
+ * driven phase by phase (used for P-sharding across GPUs), and stage-level calls that mirror the
+ * reference's kernel-wrapper level for parity tests.
+ *
+ * Conventions
+ *   - Host clouds are row-major n x 3 doubles, like the reference's CPUMatrix (include/libalg/CPUMatrix.hpp:9-14).
+ *   - Every function returns ICP_AMD_OK (0) or a negative ICP_AMD_E* code; icp_amd_last_error() gives the
+ *     text (thread-local).  Nothing exits, aborts or throws across this boundary (the reference exit(1)s
+ *     on device errors, include/error.cuh:3-9, and throws std::runtime_error on argument errors,
+ *     include/error.hpp:6-15; the GPUICP executable built on this ABI restores those behaviours).
+ *   - There is no CPU fallback: without a HIP device every compute entry point fails with ICP_AMD_ENODEV.
+ *   - Results follow the reference CPU path (src/cpu/icp.cpp:194-229): correspondence = first minimum of
+ *     sqrt(sqrt(d^2)) with d^2 accumulated without FMA, cov = sum q (x) p, R = U V^T without reflection
+ *     fix, t = Qc - Pc R^T, P <- P R^T + t.
+ */
+#ifndef ICP_AMD_H
+#define ICP_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ICP_AMD_OK       0
+#define ICP_AMD_EINVAL  (-1)  /* bad argument, empty cloud, wrong column count, size over the limits   */
+#define ICP_AMD_ENODEV  (-2)  /* no usable HIP device                                                   */
+#define ICP_AMD_EHIP    (-3)  /* a HIP runtime call failed (text in icp_amd_last_error)                 */
+#define ICP_AMD_ENOMEM  (-4)  /* host or device allocation failed                                       */
+#define ICP_AMD_EIO     (-5)  /* file could not be opened / parsed                                      */
+#define ICP_AMD_ESTATE  (-6)  /* call sequence error (e.g. iterate before set_source)                   */
+
+/* The four method strings of the reference command line (src/gpu/main.cu:74).  All are served by the one
+ * engine (they only chose between CUDA kernel variants in the reference). */
+#define ICP_AMD_METHOD_SHARED_LOOP 0
+#define ICP_AMD_METHOD_SHARED      1
+#define ICP_AMD_METHOD_LOOP        2
+#define ICP_AMD_METHOD_BATCH       3
+
+/* Correspondence-search kernel variants (engine option `search`); every variant returns identical indices. */
+#define ICP_AMD_SEARCH_AUTO   0
+#define ICP_AMD_SEARCH_EXACT  1   /* 8 un-fused fp64 ops per pair, the oracle's own sequence                */
+#define ICP_AMD_SEARCH_FMA    2   /* fused fp64 pre-filter + exact re-evaluation of every candidate         */
+
+typedef struct icp_amd_engine icp_amd_engine;
+
+/* Per-iteration outputs, every pointer optional (NULL = not wanted). Host memory owned by the caller. */
+typedef struct icp_amd_trace {
+    double  *Pc;   /* iters x 3   centroid of the running source cloud                                    */
+    int32_t *idx;  /* iters x n   correspondence indices (reference: corresps, src/cpu/icp.cpp:210)        */
+    double  *cov;  /* iters x 9   cross-covariance, row = target axis (src/cpu/icp.cpp:108-131)            */
+    double  *S;    /* iters x 3   singular values, descending                                              */
+    double  *R;    /* iters x 9   rotation U V^T (src/cpu/icp.cpp:221)                                     */
+    double  *t;    /* iters x 3   translation (src/cpu/icp.cpp:223)                                        */
+    double  *rms;  /* iters       sqrt(mean d^2 of matched pairs), a convergence trace (not in reference)  */
+} icp_amd_trace;
+
+typedef struct icp_amd_options {
+    int    device;        /* HIP device ordinal                                                            */
+    void  *stream;        /* hipStream_t to enqueue on; NULL = the engine creates its own                 */
+    int    search;        /* ICP_AMD_SEARCH_*                                                              */
+    int    q_splits;      /* target-range splits of the search grid; 0 = heuristic                        */
+    int    kernel_timing; /* 1 = record hipEvents around every search launch (icp_amd_kernel_ms)          */
+    /* P-sharding (one engine per GPU).  world = 1: single GPU.  Rank r owns the source rows
+     * [r*rows_per_rank, min(n_global, (r+1)*rows_per_rank)), rows_per_rank a multiple of 1024. */
+    int    rank, world;
+    size_t n_global;      /* 0 = the n given to set_source                                                 */
+    /* world > 1: device buffers that the CALLER all-gathers between phases (see icp_amd_step_*).
+     * Each holds world * chunks_per_rank * width doubles, rank-major; width 12 (cov) / 3 (centroid). */
+    double *cov_gather;
+    double *cen_gather;
+    int    reserved[8];
+} icp_amd_options;
+
+const char *icp_amd_last_error(void);
+int         icp_amd_version(void);
+int         icp_amd_device_count(void);
+void        icp_amd_default_options(icp_amd_options *opt);
+/* rows per rank and 1024-row chunks per rank for a P-sharded run (pure host arithmetic). */
+size_t      icp_amd_rows_per_rank(size_t n_global, int world);
+size_t      icp_amd_chunks_per_rank(size_t n_global, int world);
+
+/* ---- whole path: replaces icp_gpu_optimized / icp_gpu (reference include/gpu/icp.cuh:38-39,
+ *      src/gpu/icp.cu:469-652, 275-445).  P, Q borrowed and not modified; P_out caller-owned n x 3. */
+int icp_amd_run(const double *P_xyz, size_t n, const double *Q_xyz, size_t m, unsigned iters,
+                int method, double *P_out, icp_amd_trace *trace);
+
+/* ---- persistent engine (replaces the allocation / H2D / loop / D2H plan of src/gpu/icp.cu:511-648) */
+int icp_amd_create(icp_amd_engine **out, const icp_amd_options *opt);
+int icp_amd_destroy(icp_amd_engine *e);
+/* Upload + centre the target once (src/gpu/icp.cu:527,537-545; oracle src/cpu/icp.cpp:197-198). */
+int icp_amd_set_target(icp_amd_engine *e, const double *Q_xyz, size_t m);
+/* Upload this rank's source rows (src/gpu/icp.cu:528). n = local rows. */
+int icp_amd_set_source(icp_amd_engine *e, const double *P_xyz, size_t n);
+/* Enqueue `iters` iterations (src/gpu/icp.cu:548-628); no host synchronisation.  world must be 1. */
+int icp_amd_iterate(icp_amd_engine *e, unsigned iters);
+/* Same, bracketed by hipEvents on the engine's stream; returns the elapsed device time. */
+int icp_amd_iterate_timed(icp_amd_engine *e, unsigned iters, double *elapsed_ms);
+/* P-sharded iteration in two phases; the caller all-gathers cov_gather after step_search and cen_gather
+ * after step_update (e.g. torch.distributed / RCCL all_gather on the same stream).
+ * With world == 1 the two calls are equivalent to icp_amd_iterate(e, 1). */
+int icp_amd_step_begin(icp_amd_engine *e);   /* centroid partials of the local rows -> cen_gather slot   */
+int icp_amd_step_search(icp_amd_engine *e);  /* centroid, search, cov partials -> cov_gather slot         */
+int icp_amd_step_update(icp_amd_engine *e);  /* solve R,t; apply; new centroid partials -> cen_gather slot */
+int icp_amd_sync(icp_amd_engine *e);
+/* Download the running source rows (src/gpu/icp.cu:629-631). Synchronises. */
+int icp_amd_get_source(icp_amd_engine *e, double *P_out);
+/* Outputs of the most recent iteration (synchronises). Any pointer may be NULL. idx: local rows. */
+int icp_amd_get_last(icp_amd_engine *e, double *Pc, int32_t *idx, double *cov, double *S, double *R,
+                     double *t, double *rms);
+int icp_amd_get_target_centroid(icp_amd_engine *e, double Qc[3]);
+/* Average / total device time of the search launches since create (kernel_timing = 1). Synchronises. */
+int icp_amd_kernel_ms(icp_amd_engine *e, double *search_avg_ms, double *search_total_ms, unsigned *launches);
+/* Launch geometry chosen for the search kernel (for reports). */
+int icp_amd_search_geometry(icp_amd_engine *e, int *points_per_lane, int *q_splits, int *workgroups, int *variant);
+
+/* ---- stage level, host pointers in and out, computed on the device with the engine's kernels.
+ *      These mirror the reference's kernel-wrapper level and exist for parity tests. */
+/* get_array_correspondences_optimized (include/libgpuicp/corresp_optimized.cuh:23-24) with the centring of
+ * P (src/gpu/icp.cu:557) fused in: idx[i] = argmin_j key(P[i]-Pc, Qz[j]).  Qz is used as given. */
+int icp_amd_correspondences(const double *P_xyz, size_t n, const double Pc[3], const double *Qz_xyz, size_t m,
+                            int search, int q_splits, int32_t *idx);
+/* get_array_cross_covs_flattened + reduce_0(SUM) (include/libgpuicp/crosscov.cuh:112-116, src/gpu/icp.cu:579-584) */
+int icp_amd_cross_cov(const double *P_xyz, size_t n, const double Pc[3], const double *Qz_xyz, size_t m,
+                      const int32_t *idx, double cov[9]);
+/* mean_0 (include/libgpualg/mean.cuh; src/gpu/icp.cu:537,551) */
+int icp_amd_centroid(const double *A_xyz, size_t n, double out[3]);
+/* svd_gpu + matrixMultiplication + gpuTranspose + matrix_op (src/gpu/icp.cu:588-611) */
+int icp_amd_solve(const double cov[9], const double Pc[3], const double Qc[3], double R[9], double t[3], double S[3]);
+/* matrixMultiplication(P, R^T) + matrix_op(ADD t) (src/gpu/icp.cu:617-626) */
+int icp_amd_apply(const double *P_xyz, size_t n, const double R[9], const double t[3], double *P_out);
+
+/* ---- host I/O kept from the reference */
+/* readCSV (include/libCSV/csv.hpp:33, src/libCSV/csv.cpp:94-158): optional header line, strtod parsing.
+ * *out is malloc'd (free with icp_amd_free). header: optional buffer for the header line. */
+int    icp_amd_read_csv(const char *path, double **out, size_t *nblines, size_t *nbcols, char *header, size_t header_cap);
+void   icp_amd_free(void *p);
+/* CPUMatrix::write_in_file / operator<< (src/libalg/CPUMatrix.cpp:81-94,323-327) */
+int    icp_amd_write_cloud(const char *path, const double *A, size_t rows, size_t cols);
+/* CPUMatrix::euclidianDistance (src/libalg/CPUMatrix.cpp:291-295) on two rows x cols clouds (host, fp64) */
+double icp_amd_euclidian_distance(const double *A, const double *B, size_t rows, size_t cols);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ICP_AMD_H */

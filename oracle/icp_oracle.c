@@ -138,12 +138,14 @@ void oracle_svd3(const double Ain[9], double U[9], double S[3], double VT[9])
         for (int j = 0; j < 2 - i; ++j)
             if (sg[ord[j]] < sg[ord[j + 1]]) { int t = ord[j]; ord[j] = ord[j + 1]; ord[j + 1] = t; }
     double u[3][3], vv[3][3];
+    /* singular values at roundoff level (<= 1e-13 * S[0]) carry no direction: treated as zero */
+    const double tol = 1e-13 * sg[ord[0]];
     int rank = 0;
     for (int j = 0; j < 3; ++j) {
         int c = ord[j];
         S[j] = sg[c];
         for (int i = 0; i < 3; ++i) vv[i][j] = v[i][c];
-        if (sg[c] > 0.0 && sg[c] >= sg[ord[0]] * 1e-290) {
+        if (sg[c] > 0.0 && sg[c] > tol && rank == j) {
             for (int i = 0; i < 3; ++i) u[i][j] = a[i][c] / sg[c];
             rank = j + 1;
         } else {
@@ -165,15 +167,24 @@ void oracle_svd3(const double Ain[9], double U[9], double S[3], double VT[9])
             if (fabs(u[2][0]) < fabs(u[m][0])) m = 2;
             double e[3] = {0, 0, 0};
             e[m] = 1.0;
-            double w[3] = {u[1][0] * e[2] - u[2][0] * e[1], u[2][0] * e[0] - u[0][0] * e[2], u[0][0] * e[1] - u[1][0] * e[0]};
-            double nw = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
-            for (int i = 0; i < 3; ++i) u[i][1] = w[i] / nw;
+            u[0][1] = u[1][0] * e[2] - u[2][0] * e[1];
+            u[1][1] = u[2][0] * e[0] - u[0][0] * e[2];
+            u[2][1] = u[0][0] * e[1] - u[1][0] * e[0];
         }
-        if (rank <= 2) {
-            u[0][2] = sgn * (u[1][0] * u[2][1] - u[2][0] * u[1][1]);
-            u[1][2] = sgn * (u[2][0] * u[0][1] - u[0][0] * u[2][1]);
-            u[2][2] = sgn * (u[0][0] * u[1][1] - u[1][0] * u[0][1]);
-        }
+        /* Gram-Schmidt clean-up of u1 against u0 (a no-op to rounding when S[1] is well above tol) */
+        double d01 = u[0][0] * u[0][1] + u[1][0] * u[1][1] + u[2][0] * u[2][1];
+        for (int i = 0; i < 3; ++i) u[i][1] -= d01 * u[i][0];
+        double n1 = sqrt(u[0][1] * u[0][1] + u[1][1] * u[1][1] + u[2][1] * u[2][1]);
+        for (int i = 0; i < 3; ++i) u[i][1] /= n1;
+        /* third column: +-(u0 x u1); the sign follows the data when S[2] is significant, otherwise
+         * det(U) = det(V) (proper rotation on the null space) */
+        double w[3] = {u[1][0] * u[2][1] - u[2][0] * u[1][1],
+                       u[2][0] * u[0][1] - u[0][0] * u[2][1],
+                       u[0][0] * u[1][1] - u[1][0] * u[0][1]};
+        double s3 = sgn;
+        if (rank == 3)
+            s3 = (w[0] * u[0][2] + w[1] * u[1][2] + w[2] * u[2][2]) < 0 ? -1.0 : 1.0;
+        for (int i = 0; i < 3; ++i) u[i][2] = s3 * w[i];
     }
     for (int i = 0; i < 3; ++i)
         for (int j = 0; j < 3; ++j) {

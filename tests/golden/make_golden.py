@@ -89,7 +89,8 @@ def run_icp_case(name, P, Q, iters, keep_p=None, pfile=None, qfile=None):
     assert np.array_equal(tr["P_in"][0], P), name
     keep = list(range(iters)) if keep_p is None else [k for k in keep_p if k < iters]
     tr["P_in_iters"] = np.array(keep, dtype=np.int32)
-    tr["P_in"] = tr["P_in"][keep]
+    # iteration 0 starts from P itself (asserted above): not stored twice; conftest.golden() re-inserts it
+    tr["P_in"] = tr["P_in"][[k for k in keep if k > 0]]
     np.savez_compressed(os.path.join(HERE, name + ".npz"), P=P, Q=Q, iters=np.int32(iters), **tr)
     print("%-14s N=%d M=%d iters=%d  -> %s.npz" % (name, len(P), len(Q), iters, name))
 

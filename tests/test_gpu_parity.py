@@ -1,0 +1,183 @@
+"""GPU parity tests (run on the MI355X box with -m gpu): the HIP path, called through the C ABI of
+libicp_amd.so, against golden vectors from the unmodified reference and against the CPU oracle.
+Bar: correspondence indices bit-exact; cov, R, t, P within 1e-9 relative (north_star), fp64."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import icp_amd
+from conftest import ICP_CASES, ROOT, golden, relerr, relerr_t
+from icp_amd import synth
+from oracle import pyoracle as orc
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-9
+
+
+def test_device_fourth_root_is_correctly_rounded():
+    """The comparison key sqrt(sqrt(d2)) must round exactly like the host's (IEEE correctly rounded sqrt)."""
+    import ctypes as C
+    rng = np.random.RandomState(1)
+    x = np.concatenate([rng.uniform(0, 4, 400000), 10.0 ** rng.uniform(-300, 300, 400000),
+                        np.array([0.0, 1.0, np.nextafter(1.0, 2.0), np.nextafter(1.0, 0.0), 5e-324, 1.7e308, np.inf])])
+    # neighbourhoods of key-preimage edges: x = k^4 +- a few ulp
+    k = rng.uniform(0.01, 3, 100000)
+    e = (k * k) * (k * k)
+    for s in range(-4, 5):
+        x = np.concatenate([x, e * (1 + s * 2.0 ** -52)])
+    out = np.empty_like(x)
+    icp_amd.check(icp_amd.lib().icp_amd_test_fourth_root(x.ctypes.data_as(C.c_void_p), C.c_size_t(len(x)),
+                                                            out.ctypes.data_as(C.c_void_p)))
+    assert np.array_equal(out, np.sqrt(np.sqrt(x)))
+
+
+@pytest.mark.parametrize("name", ICP_CASES)
+def test_stagewise_against_reference(name):
+    g = golden(name)
+    Q, Qc = g["Q"], g["Qc"]
+    assert relerr(icp_amd.centroid(Q), Qc) < 1e-13
+    Qz = Q - Qc                                      # same IEEE subtraction as the reference's Q -= Q_center
+    for slot, it in enumerate(g["P_in_iters"]):
+        P_in, Pc = g["P_in"][slot], g["Pc"][it]
+        assert relerr(icp_amd.centroid(P_in), Pc) < 1e-13
+        for search, splits in (("exact", 1), ("fma", 1), ("exact", 3), ("fma", 5)):
+            idx = icp_amd.correspondences(P_in, Pc, Qz, search=search, q_splits=splits)
+            assert np.array_equal(idx, g["idx"][it]), (name, it, search, splits, int((idx != g["idx"][it]).sum()))
+        cov = icp_amd.cross_cov(P_in, Pc, Qz, g["idx"][it])
+        assert relerr(cov, g["cov"][it]) < 1e-12, (name, it)
+        R, t, S = icp_amd.solve(g["cov"][it], Pc, Qc)
+        assert relerr(R, g["R"][it]) < TOL and relerr(S, g["S"][it]) < TOL
+        assert relerr_t(t, g["t"][it], Qc, Pc) < TOL
+        P_next = icp_amd.apply(P_in, g["R"][it], g["t"][it])
+        assert np.array_equal(P_next, orc.apply(P_in, g["R"][it], g["t"][it]))   # un-fused, same order: bit-exact
+
+
+@pytest.mark.parametrize("name", ICP_CASES)
+def test_whole_loop_against_reference(name):
+    g = golden(name)
+    iters = int(g["iters"])
+    P_out, tr = icp_amd.icp_gpu_optimized(g["P"], g["Q"], iters, "-shared-loop", trace=True)
+    mism = int((tr["idx"] != g["idx"]).sum())
+    assert mism == 0, "%s: %d correspondence mismatches" % (name, mism)
+    assert relerr(tr["Pc"], g["Pc"]) < TOL
+    assert relerr(tr["cov"], g["cov"]) < TOL
+    assert relerr(tr["R"], g["R"]) < TOL
+    for it in range(iters):
+        assert relerr_t(tr["t"][it], g["t"][it], g["Qc"], g["Pc"][it]) < TOL
+    assert relerr(P_out, g["P_out"]) < TOL
+
+
+@pytest.mark.parametrize("method", ["-loop", "-shared", "-shared-loop", "-batch"])
+def test_all_method_flags_give_the_same_result(method):
+    g = golden("syn256")
+    P_out = icp_amd.icp_gpu_optimized(g["P"], g["Q"], 3, method)
+    ref = icp_amd.icp_gpu_optimized(g["P"], g["Q"], 3, "-shared-loop")
+    assert np.array_equal(P_out, ref)
+    with pytest.raises(icp_amd.IcpAmdError):
+        icp_amd.icp_gpu_optimized(g["P"], g["Q"], 3, "-fast")
+
+
+def test_adversarial_ties():
+    g = golden("ties_corr")
+    for search in ("exact", "fma"):
+        for splits in (1, 2):
+            idx = icp_amd.correspondences(g["Pz"], np.zeros(3), g["Qz"], search=search, q_splits=splits)
+            assert np.array_equal(idx, g["idx"]), (search, splits)
+
+
+def test_edge_shapes():
+    rng = np.random.RandomState(3)
+    for n, m in ((1, 1), (1, 5), (7, 1), (63, 65), (1025, 1023), (300, 2049), (2050, 257)):
+        P, Q = rng.randn(n, 3), rng.randn(m, 3)
+        Pc = orc.mean0(P)
+        Qz = Q - orc.mean0(Q)
+        want = orc.correspondences(P - Pc, Qz)
+        for search in ("exact", "fma"):
+            assert np.array_equal(icp_amd.correspondences(P, Pc, Qz, search=search, q_splits=2), want), (n, m)
+        out = orc.icp(P, Q, 2, trace=True)
+        P_out, tr = icp_amd.icp_gpu_optimized(P, Q, 2, trace=True)
+        assert np.array_equal(tr["idx"], out["idx"])
+        if n >= 7 and m >= 5:   # tiny clouds give singular covariances: only the cloud itself is compared there
+            assert relerr(tr["R"], out["R"]) < TOL
+        assert relerr(P_out, out["P_out"]) < 1e-8
+    for P, Q in ((np.zeros((0, 3)), np.zeros((4, 3))), (np.zeros((4, 3)), np.zeros((0, 3)))):
+        with pytest.raises(icp_amd.IcpAmdError):
+            icp_amd.icp_gpu_optimized(P, Q, 1)
+    with pytest.raises(icp_amd.IcpAmdError):
+        icp_amd.icp_gpu_optimized(np.zeros((4, 2)), np.zeros((4, 3)), 1)
+
+
+def test_duplicate_and_identical_clouds():
+    """P == a permutation of Q: every point finds its own copy (index = inverse permutation), R = I, t = 0."""
+    rng = np.random.RandomState(5)
+    Q = rng.uniform(-1, 1, (5000, 3))
+    perm = rng.permutation(5000)
+    P = Q[perm]
+    P_out, tr = icp_amd.icp_gpu_optimized(P, Q, 2, trace=True)
+    assert np.array_equal(tr["idx"][0], perm)
+    assert relerr(tr["R"][0], np.eye(3)) < 1e-12
+    assert np.abs(P_out - P).max() < 1e-12
+
+
+def test_full_size_properties_c3():
+    """BASELINE config 3 size (100k x 100k): sampled rows against the oracle, determinism, and independence
+    of the launch geometry (target splits, points per lane, kernel variant)."""
+    P, Q = synth.make_pair(100000, 100000)
+    results = []
+    for kw in (dict(search="exact"), dict(search="fma"), dict(search="exact", q_splits=7), dict(search="exact")):
+        e = icp_amd.Engine(**kw)
+        e.set_target(Q)
+        e.set_source(P)
+        e.iterate(2)
+        last = e.get_last()
+        results.append((last, e.get_source()))
+        Qc = e.target_centroid()
+        e.close()
+    base, P_base = results[0]
+    for last, P_out in results[1:]:
+        assert np.array_equal(last["idx"], base["idx"])
+        assert np.array_equal(last["cov"], base["cov"])      # fixed-order reductions: bit-identical
+        assert np.array_equal(P_out, P_base)
+    # sampled oracle check of the first iteration
+    e = icp_amd.Engine()
+    e.set_target(Q)
+    e.set_source(P)
+    e.iterate(1)
+    last = e.get_last()
+    e.close()
+    rows = np.random.RandomState(9).choice(100000, 1500, replace=False)
+    Pc = orc.mean0(P)
+    assert relerr(last["Pc"], Pc) < 1e-13
+    want = orc.correspondences((P - last["Pc"])[rows], Q - Qc, nthreads=8)
+    assert np.array_equal(last["idx"][rows], want)
+    cov = orc.cross_cov(P - last["Pc"], Q - Qc, last["idx"])
+    assert relerr(last["cov"], cov) < 1e-11
+    # the registration converges on this pair: rms falls to the noise level (sigma = 1e-3 per axis)
+    assert base["rms"] < 5e-3
+
+
+def test_cli_matches_reference_output(tmp_path):
+    """GPUICP on the 30-point pair: same stdout line shape, same output file format as the reference
+    (reference src/gpu/main.cu:79-80); usage and method errors abort like runtime_assert."""
+    exe = os.path.join(ROOT, "bin", "GPUICP")
+    g = golden("c1_30pts")
+    pf, qf = tmp_path / "P.txt", tmp_path / "Q.txt"
+    for path, A in ((pf, g["P"]), (qf, g["Q"])):
+        with open(path, "w") as f:
+            f.write("Points_0,Points_1,Points_2\n")
+            for r in A:
+                f.write("%.17g,%.17g,%.17g\n" % tuple(r))
+    r = subprocess.run([exe, str(pf), str(qf), "5", "-shared-loop"], cwd=tmp_path, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.startswith("Squared actual mean diff: ")
+    assert float(r.stdout.split(":")[1]) < 1e-12
+    lines = open(tmp_path / "point_cloud_result").read().split("\n")
+    assert lines[0] == " dim0: 30 dim1: 3 array: "
+    got = np.array([[float(v) for v in ln.split()] for ln in lines[1:31]])
+    assert np.abs(got - g["P_out"]).max() < 1e-4      # the file carries 6 significant digits
+    r = subprocess.run([exe, str(pf), str(qf), "5"], cwd=tmp_path, capture_output=True, text=True, timeout=60)
+    assert r.returncode != 0 and "Usage: ./GPUICP file1 file2 nbiters method" in r.stderr
+    r = subprocess.run([exe, str(pf), str(qf), "5", "-fast"], cwd=tmp_path, capture_output=True, text=True, timeout=60)
+    assert r.returncode != 0 and "Invalid method, must be: -shared|-loop|-shared-loop|-batch" in r.stderr

@@ -1,0 +1,95 @@
+"""CPU tests (no GPU): the C-ABI library loads and exports every declared symbol, the host-side pieces kept
+from the reference (CSV loader, writer, final report) behave like the reference, and the compute entry
+points fail loudly without a device (no CPU fallback)."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import icp_amd
+from conftest import ROOT, golden
+from oracle import pyoracle as orc
+
+REF_DATA = "/root/reference/data"
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "icp_amd.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    names = set(re.findall(r"\b(icp_amd_[a-z_0-9]+)\s*\(", hdr))
+    assert len(names) >= 30
+    L = icp_amd.lib()
+    for n in sorted(names):
+        assert hasattr(L, n), "libicp_amd.so does not export %s" % n
+
+
+def test_no_cpu_fallback():
+    if icp_amd.device_count() > 0:
+        pytest.skip("a GPU is present")
+    P = np.zeros((4, 3))
+    for fn in (lambda: icp_amd.icp_gpu_optimized(P, P, 1), lambda: icp_amd.centroid(P),
+               lambda: icp_amd.correspondences(P, np.zeros(3), P), lambda: icp_amd.Engine()):
+        with pytest.raises(icp_amd.IcpAmdError) as ei:
+            fn()
+        assert ei.value.code == -2 and "no CPU fallback" in str(ei.value)
+
+
+def test_sharding_arithmetic():
+    for n, g in ((1000000, 8), (1000000, 1), (1048576, 8), (100000, 4), (1, 8), (1025, 2)):
+        rpr, cpr = icp_amd.rows_per_rank(n, g), icp_amd.chunks_per_rank(n, g)
+        assert rpr == cpr * 1024 and rpr * g >= n
+        assert rpr * g - n < 1024 * g            # never more than one chunk per rank of slack
+    assert icp_amd.rows_per_rank(1000000, 8) == 125952
+
+
+def test_read_csv_matches_reference_behaviour(tmp_path):
+    g = golden("c1_30pts")
+    def w(name, text):
+        p = tmp_path / name
+        p.write_text(text)
+        return p
+    body = "".join("%.17g,%.17g,%.17g\n" % tuple(r) for r in g["P"])
+    a, h = icp_amd.read_csv(w("h.csv", "Points_0,Points_1,Points_2\n" + body))
+    assert np.array_equal(a, g["P"]) and h == "Points_0,Points_1,Points_2\n"
+    a, h = icp_amd.read_csv(w("nh.csv", body))
+    assert np.array_equal(a, g["P"]) and h == ""
+    a, _ = icp_amd.read_csv(w("ws.csv", "1.5, 2.5 ,3abc\n4,5,6\n"))       # strtod semantics: prefix parse, blanks
+    assert np.array_equal(a, [[1.5, 2.5, 3.0], [4, 5, 6]])
+    a, _ = icp_amd.read_csv(w("five.csv", "a,b,c,d,e\n1,2,3,4,5\n"))
+    assert a.shape == (1, 5)
+    for bad in ("x,y,z\n1,2,3\n\n", "1,2,3\nfoo,2,3\n", "1,2,3\n4,5\n"):
+        with pytest.raises(icp_amd.IcpAmdError):
+            icp_amd.read_csv(w("bad.csv", bad))
+    with pytest.raises(icp_amd.IcpAmdError) as ei:
+        icp_amd.read_csv(tmp_path / "missing.csv")
+    assert "File could not be opened" in str(ei.value)
+    if os.path.isdir(REF_DATA):   # the reference's own files, read in place (build container only)
+        a, _ = icp_amd.read_csv(REF_DATA + "/30points_notebook_P.txt")
+        assert np.array_equal(a, g["P"])
+        a, _ = icp_amd.read_csv(REF_DATA + "/icp/cow_tr2.txt")
+        assert a.shape == (2903, 5)
+
+
+def test_write_cloud_and_report_format(tmp_path):
+    g = golden("c1_30pts")
+    out = tmp_path / "point_cloud_result"
+    icp_amd.write_cloud(out, g["P_out"])
+    lines = out.read_text().split("\n")
+    assert lines[0] == " dim0: 30 dim1: 3 array: "
+    assert lines[1] == " ".join("%g" % v for v in g["P_out"][0]) + " "
+    d = icp_amd.euclidian_distance(g["Q"], g["P_out"])
+    assert d == orc.euclidian_distance(g["Q"], g["P_out"])
+    assert "%g" % d == "3.48782e-14"          # the value CPUICP prints for this pair
+    with pytest.raises(icp_amd.IcpAmdError):
+        icp_amd.euclidian_distance(g["Q"], g["P_out"][:5])
+
+
+def test_cli_argument_errors():
+    exe = os.path.join(ROOT, "bin", "GPUICP")
+    r = subprocess.run([exe, "a", "b"], capture_output=True, text=True)
+    assert r.returncode != 0
+    assert "Usage: ./GPUICP file1 file2 nbiters method={-loop|-batch|-shared|-shared-loop}" in r.stderr
+    r = subprocess.run([exe, "/nonexistent", "/nonexistent", "3", "-loop"], capture_output=True, text=True)
+    assert r.returncode != 0 and "File could not be opened !" in r.stderr
