@@ -109,7 +109,8 @@ struct icp_amd_engine {
     size_t stage_rows = 0;
 
     // search
-    int variant = kExact, ppl = 4, q_splits = 1;
+    int variant = kExact, ppl = 4, q_splits = 1, cb = 8;
+    bool have_prev = false;     // idx holds the previous iteration's correspondences (search seed)
     double *keys = nullptr;
     uint32_t *idxs = nullptr;
     size_t split_cap = 0;       // allocated q_splits * n_pad
@@ -243,9 +244,9 @@ static void choose_geometry(icp_amd_engine *e)
     const size_t ptiles = e->n_pad / ((size_t)kWG * ppl);
     const size_t tiles = e->m_pad / kTileQ;
     size_t splits = 1;
-    const size_t want = 8 * cus;
+    const size_t want = 64 * cus;   // measured at 1M x 1M: 8 -> 16 splits (7.8k -> 15.6k workgroups) still gains 0.5 %
     if (ptiles < want) splits = (want + ptiles - 1) / ptiles;
-    if (splits > tiles / 2) splits = tiles / 2;   // at least two LDS tiles per split
+    if (splits > tiles / 4) splits = tiles / 4;   // at least four LDS tiles per split
     if (splits > 64) splits = 64;
     if (splits < 1) splits = 1;
     if (e->opt.q_splits > 0) splits = (size_t)e->opt.q_splits;
@@ -254,7 +255,12 @@ static void choose_geometry(icp_amd_engine *e)
     if (splits > tiles) splits = tiles;
     e->ppl = ppl;
     e->q_splits = (int)splits;
-    int variant = e->opt.search == ICP_AMD_SEARCH_FMA ? kFma : kExact;
+    int cb = env_int("ICP_AMD_CB", 32);
+    if (cb != 8 && cb != 16 && cb != 32) cb = 32;
+    e->cb = cb;
+    // AUTO = the fused pre-filter: identical indices (every candidate is re-evaluated un-fused), 7.1 instead
+    // of 9.1 fp64 VALU instructions per pair
+    int variant = e->opt.search == ICP_AMD_SEARCH_EXACT ? kExact : kFma;
     const char *sv = getenv("ICP_AMD_SEARCH");
     if (sv && !strcmp(sv, "fma")) variant = kFma;
     if (sv && !strcmp(sv, "exact")) variant = kExact;
@@ -281,6 +287,7 @@ extern "C" int icp_amd_set_source(icp_amd_engine *e, const double *P, size_t n)
         e->p_store = nullptr; e->idx = nullptr; e->n_pad = 0;
         HIPCHK(hipMalloc(&e->p_store, 3 * n_pad * sizeof(double)));
         HIPCHK(hipMalloc(&e->idx, n_pad * sizeof(uint32_t)));
+        HIPCHK(hipMemset(e->idx, 0xFF, n_pad * sizeof(uint32_t)));
         e->n_pad = n_pad;
         e->P = Soa3{e->p_store, e->p_store + n_pad, e->p_store + 2 * n_pad};
     }
@@ -322,6 +329,7 @@ extern "C" int icp_amd_set_source(icp_amd_engine *e, const double *P, size_t n)
     HIPCHK(aos_to_soa(e->stream, e->stage, n, n_pad, nullptr, 0.0, e->P));
     HIPCHK(hipStreamSynchronize(e->stream));  // P may be reused by the caller after return
     e->have_source = true;
+    e->have_prev = false;
     e->cen_ready = false;
     return ICP_AMD_OK;
 }
@@ -379,9 +387,12 @@ extern "C" int icp_amd_step_search(icp_amd_engine *e)
             if (e->ev_used >= 4096) RCCHK(drain_events(e));
             RCCHK(time_begin(e, &a, &b));
         }
-        HIPCHK(search(e->stream, e->variant, e->ppl, e->P, e->n_pad, e->pc, e->Qz, e->m_pad, e->q_splits, e->keys, e->idxs));
+        const bool seed = e->have_prev && env_int("ICP_AMD_SEED", 1) != 0;
+        HIPCHK(search(e->stream, e->variant, e->ppl, e->cb, e->P, e->n_pad, e->pc, e->Qz, e->m, e->m_pad, e->q_splits,
+                      seed ? e->idx : nullptr, e->keys, e->idxs));
         if (e->opt.kernel_timing) HIPCHK(hipEventRecord(b, e->stream));
         HIPCHK(merge_cov(e->stream, e->P, e->n, e->n_pad, e->pc, e->Qz, e->m, e->q_splits, e->keys, e->idxs, e->idx, cov_slot));
+        e->have_prev = true;
     }
     return ICP_AMD_OK;
 }
@@ -589,7 +600,10 @@ extern "C" int icp_amd_correspondences(const double *P, size_t n, const double P
     HIPCHK(out.alloc(n_pad * sizeof(uint32_t)));
     HIPCHK(part.alloc((n_pad / kChunk) * kCovW * sizeof(double)));
     const int variant = search_variant == ICP_AMD_SEARCH_FMA ? kFma : kExact;
-    HIPCHK(search(s, variant, ppl, dP, n_pad, pc.as<double>(), dQ, m_pad, q_splits, keys.as<double>(), idxs.as<uint32_t>()));
+    int cb = env_int("ICP_AMD_CB", 32);
+    if (cb != 8 && cb != 16 && cb != 32) cb = 32;
+    HIPCHK(search(s, variant, ppl, cb, dP, n_pad, pc.as<double>(), dQ, m, m_pad, q_splits, nullptr, keys.as<double>(),
+                  idxs.as<uint32_t>()));
     HIPCHK(merge_cov(s, dP, n, n_pad, pc.as<double>(), dQ, m, q_splits, keys.as<double>(), idxs.as<uint32_t>(),
                      out.as<uint32_t>(), part.as<double>()));
     HIPCHK(hipMemcpyAsync(idx, out.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost, s));

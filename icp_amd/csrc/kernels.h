@@ -31,8 +31,11 @@ hipError_t soa_to_aos(hipStream_t s, Soa3 in, size_t n, double *aos);
 // Brute-force nearest neighbour: for source row i (centred on the fly with pc) and target split y,
 // (key, idx) of the lexicographically smallest (sqrt(sqrt(d^2)), j) over the split's target range.
 // out_key / out_idx are [q_splits][n_pad].  n_pad multiple of 256*ppl, m_pad multiple of kTileQ.
-hipError_t search(hipStream_t s, int variant, int ppl, Soa3 P, size_t n_pad, const double *pc,
-                  Soa3 Qz, size_t m_pad, int q_splits, double *out_key, uint32_t *out_idx);
+// ppl in {1,2,4} source points per lane, cb in {8,16,32} targets between event checks.
+// idx_prev: optional seed (previous iteration's correspondences, n_pad entries, >= m means "none").
+hipError_t search(hipStream_t s, int variant, int ppl, int cb, Soa3 P, size_t n_pad, const double *pc,
+                  Soa3 Qz, size_t m, size_t m_pad, int q_splits, const uint32_t *idx_prev, double *out_key,
+                  uint32_t *out_idx);
 
 // Merge the splits (lowest index among equal keys), write idx[n], and reduce q (x) p per 1024-row chunk
 // into partial[chunk][12].

@@ -151,16 +151,17 @@ __device__ __forceinline__ double d2_fused(double ax, double ay, double az, doub
 // The oracle's comparison key (src/cpu/icp.cpp:83 on top of CPUMatrix.cpp:291-295): sqrt applied twice.
 __device__ __forceinline__ double key_of(double d2) { return sqrt(sqrt(d2)); }
 
-constexpr int kCB = 8;  // targets per unrolled block between two event checks
-
-// Slow path, entered by the lanes whose running minimum dropped inside the last block of kCB targets:
+// Slow path, entered by the lanes whose running minimum dropped inside the last block of CB targets:
 // re-evaluates the block un-fused, in target order, and updates the lexicographic best (key, index).
-// Invariant on exit: bd = smallest exact d^2 seen so far, and every target that can still beat
-// (bk, bj) has d^2 < bd (key is a monotone function of d^2, targets arrive in ascending index order).
+// Invariant on exit: every target not yet scanned that can still beat (bk, bj) has d^2 < bd
+// (key is a monotone function of d^2; targets arrive in ascending index order; a seed taken from the
+// previous iteration may have a higher index than targets still to come, hence the index compare).
+template <int CB>
 __device__ __forceinline__ void rescan_block(double ax, double ay, double az, const double *sx, const double *sy,
                                              const double *sz, int j0, unsigned jglobal, double &bd, double &bk, uint32_t &bj)
 {
-    for (int u = 0; u < kCB; ++u) {
+#pragma unroll 1
+    for (int u = 0; u < CB; ++u) {
         const double d = d2_exact(ax, ay, az, sx[j0 + u], sy[j0 + u], sz[j0 + u]);
         if (d < bd) {
             bd = d;
@@ -177,14 +178,21 @@ __device__ __forceinline__ void rescan_block(double ax, double ay, double az, co
 // grid = (n_pad / (256*PPL), q_splits).  Every lane owns PPL source points (kept in registers, centred
 // on load); the workgroup streams its target range through a 24 KB SoA LDS tile, and all lanes of a wave
 // read the same target (LDS broadcast), so the inner loop is pure fp64 VALU: 8 ops per pair for the
-// distance (6 in the fused pre-filter) + 1 v_min_f64.  Indices are not tracked in the fast path at all.
-template <int PPL, int MODE>
+// distance (6 in the fused pre-filter) + 1 v_min_f64.  Indices are not tracked in the fast path at all:
+// once per CB targets each lane checks whether its running minimum moved, and only then does the wave
+// take the slow path above.
+//
+// idx_prev (optional): last iteration's correspondence of every source point.  It is a legitimate
+// candidate, so seeding (bk, bj) with it changes nothing in the result (the order on (key, index) is
+// total) -- it only makes the running minimum tight from the first target on, so that almost no block
+// takes the slow path, in every target split.
+template <int PPL, int MODE, int CB>
 __global__ __launch_bounds__(kWG) void search_kernel(const double *__restrict__ px, const double *__restrict__ py,
                                                      const double *__restrict__ pz, const double *__restrict__ pc,
                                                      const double *__restrict__ qx, const double *__restrict__ qy,
-                                                     const double *__restrict__ qz, unsigned n_pad, unsigned m_pad,
-                                                     unsigned q_per_split, double *__restrict__ out_key,
-                                                     uint32_t *__restrict__ out_idx)
+                                                     const double *__restrict__ qz, unsigned n_pad, unsigned m, unsigned m_pad,
+                                                     unsigned q_per_split, const uint32_t *__restrict__ idx_prev,
+                                                     double *__restrict__ out_key, uint32_t *__restrict__ out_idx)
 {
     __shared__ double sq[3][kTileQ];
     const unsigned tid = threadIdx.x;
@@ -192,7 +200,7 @@ __global__ __launch_bounds__(kWG) void search_kernel(const double *__restrict__ 
     const double c0 = pc[0], c1 = pc[1], c2 = pc[2];
 
     double ax[PPL], ay[PPL], az[PPL];  // centred source points: P = P_copy - P_center (src/cpu/icp.cpp:208)
-    double m[PPL];                     // running minimum in filter space, starts each block at thr
+    double m_[PPL];                    // running minimum in filter space, starts each block at thr
     double thr[PPL];                   // filter-space image of bd
     double bd[PPL], bk[PPL];
     uint32_t bj[PPL];
@@ -204,8 +212,21 @@ __global__ __launch_bounds__(kWG) void search_kernel(const double *__restrict__ 
         bd[s] = INFINITY;  // oracle: min_dist = DBL_MAX on the key, i.e. any finite d^2 is accepted
         bk[s] = INFINITY;
         bj[s] = 0xFFFFFFFFu;
-        thr[s] = INFINITY;
-        m[s] = INFINITY;
+        if (idx_prev) {
+            const uint32_t js = idx_prev[base + s * kWG];
+            if (js < m) {
+                const double d = d2_exact(ax[s], ay[s], az[s], qx[js], qy[js], qz[js]);
+                if (d < INFINITY) {
+                    bk[s] = key_of(d);
+                    bj[s] = js;
+                    // targets with the same key and a lower index must still get through: their d^2 lies within a
+                    // few ulp of d (the fourth root merges at most ~8 neighbouring doubles), far inside this margin
+                    bd[s] = __builtin_fma(d, 1.0 + 0x1p-48, 1e-300);
+                }
+            }
+        }
+        thr[s] = (MODE == kFma) ? __builtin_fma(bd[s], 1.0 + 0x1p-49, 1e-300) : bd[s];
+        m_[s] = __builtin_fmin(thr[s], INFINITY);
     }
 
     const unsigned q0 = blockIdx.y * q_per_split;
@@ -218,29 +239,29 @@ __global__ __launch_bounds__(kWG) void search_kernel(const double *__restrict__ 
             sq[2][k] = qz[t0 + k];
         }
         __syncthreads();
-        for (int j0 = 0; j0 < kTileQ; j0 += kCB) {
+        for (int j0 = 0; j0 < kTileQ; j0 += CB) {
 #pragma unroll
-            for (int u = 0; u < kCB; ++u) {
+            for (int u = 0; u < CB; ++u) {
                 const double tx = sq[0][j0 + u], ty = sq[1][j0 + u], tz = sq[2][j0 + u];
 #pragma unroll
                 for (int s = 0; s < PPL; ++s) {
                     const double d = (MODE == kFma) ? d2_fused(ax[s], ay[s], az[s], tx, ty, tz)
                                                     : d2_exact(ax[s], ay[s], az[s], tx, ty, tz);
-                    m[s] = __builtin_fmin(m[s], d);
+                    m_[s] = __builtin_fmin(m_[s], d);
                 }
             }
             bool ev = false;
 #pragma unroll
-            for (int s = 0; s < PPL; ++s) ev |= (m[s] < thr[s]);
+            for (int s = 0; s < PPL; ++s) ev |= (m_[s] < thr[s]);
             if (ev) {
 #pragma unroll
                 for (int s = 0; s < PPL; ++s) {
-                    if (m[s] < thr[s]) {
-                        rescan_block(ax[s], ay[s], az[s], sq[0], sq[1], sq[2], j0, t0 + (unsigned)j0, bd[s], bk[s], bj[s]);
+                    if (m_[s] < thr[s]) {
+                        rescan_block<CB>(ax[s], ay[s], az[s], sq[0], sq[1], sq[2], j0, t0 + (unsigned)j0, bd[s], bk[s], bj[s]);
                         // fused and un-fused d^2 agree within (1+u)^6: any target with exact d^2 < bd has a
                         // fused d^2 below bd*(1+2^-49) (+ a subnormal-range guard)
                         thr[s] = (MODE == kFma) ? __builtin_fma(bd[s], 1.0 + 0x1p-49, 1e-300) : bd[s];
-                        m[s] = thr[s];
+                        m_[s] = __builtin_fmin(thr[s], INFINITY);
                     }
                 }
             }
@@ -282,11 +303,12 @@ __global__ __launch_bounds__(kWG) void cov_kernel(const double *__restrict__ px,
             if (MERGE) {
                 double bk = keys[i];
                 j = idxs[i];
-                for (int y = 1; y < q_splits; ++y) {  // ascending target ranges: strict < keeps the lowest index
+                for (int y = 1; y < q_splits; ++y) {  // lexicographic (key, index): a split may report the seed
                     const double ky = keys[(size_t)y * n_pad + i];
-                    if (ky < bk) {
+                    const uint32_t jy = idxs[(size_t)y * n_pad + i];
+                    if (ky < bk || (ky == bk && jy < j)) {
                         bk = ky;
-                        j = idxs[(size_t)y * n_pad + i];
+                        j = jy;
                     }
                 }
                 idx_out[i] = j;
@@ -503,32 +525,33 @@ hipError_t soa_to_aos(hipStream_t s, Soa3 in, size_t n, double *aos)
     return hipGetLastError();
 }
 
-template <int PPL>
-static hipError_t search_ppl(hipStream_t s, int variant, Soa3 P, size_t n_pad, const double *pc, Soa3 Qz, size_t m_pad,
-                             int q_splits, double *out_key, uint32_t *out_idx)
+template <int PPL, int CB>
+static hipError_t search_launch(hipStream_t s, int variant, Soa3 P, size_t n_pad, const double *pc, Soa3 Qz, size_t m,
+                                size_t m_pad, int q_splits, const uint32_t *idx_prev, double *out_key, uint32_t *out_idx)
 {
     const size_t tiles = m_pad / kTileQ;
     const unsigned q_per_split = (unsigned)(((tiles + q_splits - 1) / q_splits) * kTileQ);
     dim3 grid((unsigned)(n_pad / (kWG * PPL)), (unsigned)q_splits);
     if (variant == kFma)
-        search_kernel<PPL, kFma><<<grid, kWG, 0, s>>>(P.x, P.y, P.z, pc, Qz.x, Qz.y, Qz.z, (unsigned)n_pad, (unsigned)m_pad,
-                                                      q_per_split, out_key, out_idx);
+        search_kernel<PPL, kFma, CB><<<grid, kWG, 0, s>>>(P.x, P.y, P.z, pc, Qz.x, Qz.y, Qz.z, (unsigned)n_pad, (unsigned)m,
+                                                          (unsigned)m_pad, q_per_split, idx_prev, out_key, out_idx);
     else
-        search_kernel<PPL, kExact><<<grid, kWG, 0, s>>>(P.x, P.y, P.z, pc, Qz.x, Qz.y, Qz.z, (unsigned)n_pad,
-                                                        (unsigned)m_pad, q_per_split, out_key, out_idx);
+        search_kernel<PPL, kExact, CB><<<grid, kWG, 0, s>>>(P.x, P.y, P.z, pc, Qz.x, Qz.y, Qz.z, (unsigned)n_pad, (unsigned)m,
+                                                            (unsigned)m_pad, q_per_split, idx_prev, out_key, out_idx);
     return hipGetLastError();
 }
 
-hipError_t search(hipStream_t s, int variant, int ppl, Soa3 P, size_t n_pad, const double *pc, Soa3 Qz, size_t m_pad,
-                  int q_splits, double *out_key, uint32_t *out_idx)
+hipError_t search(hipStream_t s, int variant, int ppl, int cb, Soa3 P, size_t n_pad, const double *pc, Soa3 Qz, size_t m,
+                  size_t m_pad, int q_splits, const uint32_t *idx_prev, double *out_key, uint32_t *out_idx)
 {
-    if (n_pad == 0 || m_pad == 0 || n_pad % kChunk || m_pad % kTileQ || q_splits < 1) return hipErrorInvalidValue;
-    switch (ppl) {
-    case 1: return search_ppl<1>(s, variant, P, n_pad, pc, Qz, m_pad, q_splits, out_key, out_idx);
-    case 2: return search_ppl<2>(s, variant, P, n_pad, pc, Qz, m_pad, q_splits, out_key, out_idx);
-    case 4: return search_ppl<4>(s, variant, P, n_pad, pc, Qz, m_pad, q_splits, out_key, out_idx);
-    default: return hipErrorInvalidValue;
-    }
+    if (n_pad == 0 || m_pad == 0 || n_pad % kChunk || m_pad % kTileQ || q_splits < 1 || m > m_pad) return hipErrorInvalidValue;
+#define ICPK_CASE(PPL_, CB_) \
+    if (ppl == PPL_ && cb == CB_) return search_launch<PPL_, CB_>(s, variant, P, n_pad, pc, Qz, m, m_pad, q_splits, idx_prev, out_key, out_idx);
+    ICPK_CASE(1, 8) ICPK_CASE(1, 16) ICPK_CASE(1, 32)
+    ICPK_CASE(2, 8) ICPK_CASE(2, 16) ICPK_CASE(2, 32)
+    ICPK_CASE(4, 8) ICPK_CASE(4, 16) ICPK_CASE(4, 32)
+#undef ICPK_CASE
+    return hipErrorInvalidValue;
 }
 
 hipError_t merge_cov(hipStream_t s, Soa3 P, size_t n, size_t n_pad, const double *pc, Soa3 Qz, size_t m, int q_splits,
