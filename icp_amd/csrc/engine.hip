@@ -296,7 +296,8 @@ extern "C" int icp_amd_set_source(icp_amd_engine *e, const double *P, size_t n)
     e->cpr = cpr;
     e->chunks_local = (n + kChunk - 1) / kChunk;
     const size_t total = cpr * (size_t)world;
-    if (world > 1) {
+    if (e->opt.cov_gather && e->opt.cen_gather) {   // caller-owned exchange buffers (required when world > 1)
+        if (e->own_part) { free_dev(e->cov_part); free_dev(e->cen_part); }
         e->cov_part = e->opt.cov_gather;
         e->cen_part = e->opt.cen_gather;
         e->own_part = false;

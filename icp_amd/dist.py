@@ -45,7 +45,7 @@ class ShardedIcp:
         n_global = len(P)
         lo, hi = shard_bounds(n_global, rank, world)
         self.lo, self.hi, self.n_local, self.n_global = lo, hi, hi - lo, n_global
-        self.cov = self.cen = None
+        self.cov = self.cen = self.stream = None
         kw = dict(device=device, search=search, kernel_timing=kernel_timing)
         if world > 1:
             import torch
@@ -54,25 +54,38 @@ class ShardedIcp:
             self.cov = torch.zeros(world * cpr * COV_W, dtype=torch.float64, device=dev)
             self.cen = torch.zeros(world * cpr * CEN_W, dtype=torch.float64, device=dev)
             torch.cuda.synchronize(dev)
-            kw.update(stream=torch.cuda.current_stream(dev).cuda_stream, rank=rank, world=world, n_global=n_global,
+            # a stream of our own: torch's default stream has handle 0, which the C ABI reads as "create one", and
+            # the collectives must be ordered with the engine's kernels (torch syncs its NCCL stream with the
+            # stream that is current when the collective is issued)
+            self.stream = torch.cuda.Stream(dev)
+            kw.update(stream=self.stream.cuda_stream, rank=rank, world=world, n_global=n_global,
                       cov_gather=self.cov.data_ptr(), cen_gather=self.cen.data_ptr())
         self.engine = Engine(**kw)
         self.engine.set_target(Q)
         self.engine.set_source(np.ascontiguousarray(P[lo:hi]))
 
+    def _on_stream(self):
+        if self.stream is None:
+            import contextlib
+            return contextlib.nullcontext()
+        import torch
+        return torch.cuda.stream(self.stream)
+
     def begin(self):
-        self.engine.step_begin()
-        exchange_partials(self.cen, CEN_W, self.rank, self.world, self.group)
+        with self._on_stream():
+            self.engine.step_begin()
+            exchange_partials(self.cen, CEN_W, self.rank, self.world, self.group)
 
     def step(self):
-        self.engine.step_search()
-        exchange_partials(self.cov, COV_W, self.rank, self.world, self.group)
-        self.engine.step_update()
-        exchange_partials(self.cen, CEN_W, self.rank, self.world, self.group)
+        with self._on_stream():
+            self.engine.step_search()
+            exchange_partials(self.cov, COV_W, self.rank, self.world, self.group)
+            self.engine.step_update()
+            exchange_partials(self.cen, CEN_W, self.rank, self.world, self.group)
 
     def gather_source(self):
         """The registered cloud, assembled on every rank (host arrays)."""
-        local = self.engine.get_source()
+        local = self.engine.get_source()      # synchronises the engine's stream
         if self.world == 1:
             return local
         import torch

@@ -1,0 +1,106 @@
+"""GPU: the P-sharded path on a one-GPU box.  W engines (rank r of world W) run in one process on cuda:0 and the
+all-gathers of the per-chunk partials are emulated by device copies between the engines' exchange buffers.
+Results must be bit-identical to the single-engine run (fixed-order reductions make them independent of W)."""
+import numpy as np
+import pytest
+
+import icp_amd
+from icp_amd import dist as icpdist
+from icp_amd import synth
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def run_sharded(P, Q, world, iters):
+    n = len(P)
+    cpr = icp_amd.chunks_per_rank(n, world)
+    dev = torch.device("cuda", 0)
+    tstream = torch.cuda.Stream(dev)      # torch's default stream has handle 0 = "engine, make your own"
+    stream = tstream.cuda_stream
+    covs = [torch.zeros(world * cpr * 12, dtype=torch.float64, device=dev) for _ in range(world)]
+    cens = [torch.zeros(world * cpr * 3, dtype=torch.float64, device=dev) for _ in range(world)]
+    torch.cuda.synchronize()
+    engines = []
+    for r in range(world):
+        lo, hi = icpdist.shard_bounds(n, r, world)
+        e = icp_amd.Engine(stream=stream, rank=r, world=world, n_global=n, cov_gather=covs[r].data_ptr(),
+                           cen_gather=cens[r].data_ptr())
+        e.set_target(Q)
+        e.set_source(np.ascontiguousarray(P[lo:hi]))
+        engines.append(e)
+
+    def allgather(bufs, width):
+        per = cpr * width
+        with torch.cuda.stream(tstream):
+            for r in range(world):
+                for o in range(world):
+                    if o != r:
+                        bufs[o][r * per:(r + 1) * per].copy_(bufs[r][r * per:(r + 1) * per])
+
+    for e in engines:
+        e.step_begin()
+    allgather(cens, 3)
+    lasts = None
+    for _ in range(iters):
+        for e in engines:
+            e.step_search()
+        allgather(covs, 12)
+        for e in engines:
+            e.step_update()
+        allgather(cens, 3)
+    torch.cuda.synchronize()
+    lasts = [e.get_last() for e in engines]
+    P_out = np.concatenate([e.get_source() for e in engines])
+    for e in engines:
+        e.close()
+    return lasts, P_out
+
+
+@pytest.mark.parametrize("n,m,world", [(20000, 20000, 2), (5000, 7000, 3), (100000, 100000, 8), (1500, 1500, 4)])
+def test_sharded_equals_single(n, m, world):
+    P, Q = synth.make_pair(n, m, seed=11 + world)
+    iters = 3
+    e = icp_amd.Engine()
+    e.set_target(Q)
+    e.set_source(P)
+    e.iterate(iters)
+    single = e.get_last()
+    P_single = e.get_source()
+    e.close()
+    lasts, P_out = run_sharded(P, Q, world, iters)
+    assert np.array_equal(np.concatenate([l["idx"] for l in lasts]), single["idx"])
+    for l in lasts:                       # every rank solves redundantly: identical R, t, cov everywhere
+        for k in ("cov", "R", "t", "Pc", "S"):
+            assert np.array_equal(l[k], single[k]), k
+    assert np.array_equal(P_out, P_single)
+
+
+def test_torch_stream_and_single_rank_process_group():
+    """world = 1 through the same code path bench.py uses under torchrun (caller-owned exchange buffers on
+    torch's current stream); the all-gather of a one-rank group is the identity."""
+    P, Q = synth.make_pair(3000, 3000, seed=5)
+    dev = torch.device("cuda", 0)
+    cpr = icp_amd.chunks_per_rank(len(P), 1)
+    cov = torch.zeros(cpr * 12, dtype=torch.float64, device=dev)
+    cen = torch.zeros(cpr * 3, dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+    tstream = torch.cuda.Stream(dev)
+    e = icp_amd.Engine(stream=tstream.cuda_stream, cov_gather=cov.data_ptr(), cen_gather=cen.data_ptr())
+    e.set_target(Q)
+    e.set_source(P)
+    e.step_begin()
+    for _ in range(2):
+        e.step_search()
+        e.step_update()
+    torch.cuda.synchronize()
+    a = e.get_last()
+    # the covariance the engine solved is the in-order sum of the chunk partials it left in the caller's buffer
+    parts = cov.cpu().numpy().reshape(cpr, 12)
+    acc = np.zeros(12)
+    for r in range(cpr):
+        acc = acc + parts[r]
+    assert np.array_equal(acc[:9].reshape(3, 3), a["cov"])
+    e.close()
+    b_out, tr = icp_amd.icp_gpu_optimized(P, Q, 2, trace=True)
+    assert np.array_equal(tr["idx"][1], a["idx"]) and np.array_equal(tr["cov"][1], a["cov"])
