@@ -93,3 +93,19 @@ def test_cli_argument_errors():
     assert "Usage: ./GPUICP file1 file2 nbiters method={-loop|-batch|-shared|-shared-loop}" in r.stderr
     r = subprocess.run([exe, "/nonexistent", "/nonexistent", "3", "-loop"], capture_output=True, text=True)
     assert r.returncode != 0 and "File could not be opened !" in r.stderr
+
+
+def test_cpp_adaptor_compiles_against_reference_types(tmp_path):
+    """include/icp_amd.hpp keeps the reference's C++ signatures (include/gpu/icp.cuh:38-39): instantiate it with the
+    reference's own CPUMatrix (build container only; header-only syntax check, nothing is linked or run)."""
+    ref_inc = "/root/reference/include"
+    if not os.path.isdir(ref_inc):
+        pytest.skip("reference not mounted")
+    src = tmp_path / "adaptor.cpp"
+    src.write_text(
+        '#include "libalg/CPUMatrix.hpp"\n#include "icp_amd.hpp"\n'
+        'CPUMatrix f(CPUMatrix &P, CPUMatrix &Q, std::string &m) { return icp_amd::icp_gpu_optimized(P, Q, 3u, m); }\n'
+        'CPUMatrix g(CPUMatrix &P, CPUMatrix &Q) { return icp_amd::icp_gpu(P, Q, 3u); }\n')
+    r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-I", ref_inc, "-I", os.path.join(ROOT, "include"), str(src)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
