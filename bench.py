@@ -48,6 +48,62 @@ def cpu_baseline(P, Q, seconds_target=12.0):
             "iters_per_sec_extrapolated": (rows * m / dt) / (len(P) * float(m))}
 
 
+def bench_batch(args, rank, world, local_rank):
+    """BASELINE configs[4]: 4096 independent registrations of 1k x 1k points, 20 iterations each, split evenly over
+    the GPUs with no data-path collective (weak scaling is not meaningful: total work is fixed)."""
+    import torch
+    import icp_amd
+    from icp_amd import synth
+    per = (args.batch + world - 1) // world
+    lo, hi = min(args.batch, rank * per), min(args.batch, (rank + 1) * per)
+    n = args.batch_n
+    P, Q = synth.make_batch(min(hi - lo, 64), n, seed=synth.SEED_Q + 1000 * rank)   # 64 distinct pairs, tiled
+    reps = (hi - lo + len(P) - 1) // len(P)
+    P, Q = np.tile(P, (reps, 1, 1))[:hi - lo], np.tile(Q, (reps, 1, 1))[:hi - lo]
+    b = icp_amd.Batch(hi - lo, n, n, device=local_rank)
+    b.upload(P, Q)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            import torch.distributed as td
+            td.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        b.run(args.batch_iters)
+    barrier()
+    t0 = time.perf_counter()
+    kms = 0.0
+    for _ in range(args.steps):
+        kms += b.run(args.batch_iters, timed=True)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as td
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        td.all_reduce(tmax, op=td.ReduceOp.MAX)
+        dt = float(tmax.item())
+    if rank == 0:
+        pairs = float(args.batch) * n * n * args.batch_iters
+        ach = FLOPS_PER_PAIR * float(hi - lo) * n * n * args.batch_iters / (kms / args.steps * 1e-3)
+        print(json.dumps({
+            "metric": "distance_evals_per_sec", "value": pairs * args.steps / dt, "unit": "distance evals/s",
+            "registrations_per_sec": args.batch * args.steps / dt, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[4]: %d registrations of %d x %d points, %d iterations each, %d per GPU"
+                                   % (args.batch, n, n, args.batch_iters, hi - lo), "parallelism": "batch-split%d" % world},
+            "roofline": {"bound": "valu_fp64", "kernel": "batch_icp_kernel", "achieved": ach / 1e12, "peak": PEAK_FP64_VALU_NOFMA / 1e12,
+                         "unit": "TFLOP/s", "frac": ach / PEAK_FP64_VALU_NOFMA, "avg_launch_ms": kms / args.steps, "traffic": None}}),
+            flush=True)
+    b.close()
+    if world > 1:
+        import torch.distributed as td
+        td.barrier()
+        td.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -57,6 +113,11 @@ def main():
     ap.add_argument("--m", type=int, default=1000000, help="target points")
     ap.add_argument("--search", default=os.environ.get("ICP_AMD_SEARCH", "auto"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", default="sharded", choices=["sharded", "batch"],
+                    help="sharded: BASELINE configs[3] (default, the headline metric); batch: configs[4], 4096 x (1k x 1k)")
+    ap.add_argument("--batch", type=int, default=4096)
+    ap.add_argument("--batch-n", type=int, default=1000)
+    ap.add_argument("--batch-iters", type=int, default=20)
     args = ap.parse_args()
 
     import torch
@@ -77,6 +138,9 @@ def main():
     if world > 1:
         import torch.distributed as td
         td.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    if args.workload == "batch":
+        return bench_batch(args, rank, world, local_rank)
 
     N, M = args.n, args.m
     P, Q = synth.make_pair(N, M)          # identical on every rank (seeded)

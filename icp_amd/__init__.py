@@ -12,7 +12,7 @@ import numpy as np
 from . import _lib
 from ._lib import METHODS, SEARCH, IcpAmdError, Options, Trace, check, lib
 
-__all__ = ["icp_gpu_optimized", "icp_gpu", "Engine", "read_csv", "write_cloud", "euclidian_distance",
+__all__ = ["icp_gpu_optimized", "icp_gpu", "icp_gpu_batch", "Batch", "Engine", "read_csv", "write_cloud", "euclidian_distance",
            "correspondences", "cross_cov", "centroid", "solve", "apply", "rows_per_rank", "chunks_per_rank",
            "IcpAmdError", "device_count"]
 
@@ -143,6 +143,56 @@ class Engine:
         check(lib().icp_amd_search_geometry(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
         return dict(points_per_lane=a.value, q_splits=b.value, workgroups=c.value,
                     variant={1: "exact", 2: "fma"}.get(d.value, str(d.value)))
+
+
+class Batch:
+    """Multi-registration mode: `batch` independent (P_b, Q_b) pairs, one workgroup each (icp_amd_batch_*)."""
+
+    def __init__(self, batch, n, m, device=0):
+        self.batch, self.n, self.m = batch, n, m
+        self._h = C.c_void_p()
+        check(lib().icp_amd_batch_create(C.byref(self._h), C.c_int(device), C.c_size_t(batch), C.c_size_t(n), C.c_size_t(m)))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().icp_amd_batch_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def upload(self, P, Q):
+        P = np.ascontiguousarray(P, dtype=np.float64)
+        Q = np.ascontiguousarray(Q, dtype=np.float64)
+        if P.shape != (self.batch, self.n, 3) or Q.shape != (self.batch, self.m, 3):
+            raise IcpAmdError(_lib.EINVAL, "expected P %r and Q %r" % ((self.batch, self.n, 3), (self.batch, self.m, 3)))
+        check(lib().icp_amd_batch_upload(self._h, _p(P), _p(Q)))
+
+    def run(self, iters, search="auto", timed=False):
+        ms = C.c_double()
+        check(lib().icp_amd_batch_run(self._h, C.c_uint(iters), C.c_int(SEARCH[search]), C.byref(ms) if timed else None))
+        return ms.value if timed else None
+
+    def download(self):
+        b, n = self.batch, self.n
+        d = dict(P_out=np.empty((b, n, 3)), R=np.empty((b, 3, 3)), t=np.empty((b, 3)), cov=np.empty((b, 3, 3)),
+                 idx=np.empty((b, n), dtype=np.int32), rms=np.empty(b))
+        check(lib().icp_amd_batch_download(self._h, _p(d["P_out"]), _p(d["R"]), _p(d["t"]), _p(d["cov"]), _p(d["idx"]), _p(d["rms"])))
+        return d
+
+
+def icp_gpu_batch(P, Q, iterations):
+    """`batch` independent registrations: P [batch, n, 3], Q [batch, m, 3] -> dict(P_out, R, t, cov, idx, rms)."""
+    P = np.ascontiguousarray(P, dtype=np.float64)
+    Q = np.ascontiguousarray(Q, dtype=np.float64)
+    if P.ndim != 3 or Q.ndim != 3 or P.shape[0] != Q.shape[0] or P.shape[2] != 3 or Q.shape[2] != 3:
+        raise IcpAmdError(_lib.EINVAL, "expected P [batch, n, 3] and Q [batch, m, 3]")
+    b = Batch(P.shape[0], P.shape[1], Q.shape[1])
+    try:
+        b.upload(P, Q)
+        b.run(iterations)
+        return b.download()
+    finally:
+        b.close()
 
 
 # ---- stage level (parity tests) --------------------------------------------------------------------

@@ -109,7 +109,7 @@ struct icp_amd_engine {
     size_t stage_rows = 0;
 
     // search
-    int variant = kExact, ppl = 4, q_splits = 1, cb = 8;
+    int variant = kExact, ppl = 4, q_splits = 1, q_splits_first = 1, cb = 8;
     bool have_prev = false;     // idx holds the previous iteration's correspondences (search seed)
     double *keys = nullptr;
     uint32_t *idxs = nullptr;
@@ -235,26 +235,39 @@ extern "C" int icp_amd_set_target(icp_amd_engine *e, const double *Q, size_t m)
 // cutting the target range into pieces so short that every piece re-learns its running minimum.
 static void choose_geometry(icp_amd_engine *e)
 {
-    int ppl = 4;
     const size_t cus = (size_t)e->cu_count;
-    if (e->n_pad / (kWG * 4) < 2 * cus) ppl = 2;
-    if (e->n_pad / (kWG * 2) < 2 * cus) ppl = 1;
-    ppl = env_int("ICP_AMD_PPL", ppl);
-    if (ppl != 1 && ppl != 2 && ppl != 4) ppl = 4;
-    const size_t ptiles = e->n_pad / ((size_t)kWG * ppl);
     const size_t tiles = e->m_pad / kTileQ;
-    size_t splits = 1;
     const size_t want = 64 * cus;   // measured at 1M x 1M: 8 -> 16 splits (7.8k -> 15.6k workgroups) still gains 0.5 %
-    if (ptiles < want) splits = (want + ptiles - 1) / ptiles;
-    if (splits > tiles / 4) splits = tiles / 4;   // at least four LDS tiles per split
-    if (splits > 64) splits = 64;
-    if (splits < 1) splits = 1;
+    size_t max_splits = tiles / 4;  // at least four LDS tiles per split
+    if (max_splits > 256) max_splits = 256;
+    if (max_splits < 1) max_splits = 1;
+    // most points per lane (fewest LDS reads per pair) that still yields >= 12 workgroups per CU
+    int ppl = 1;
+    size_t splits = 1, best_wgs = 0;
+    for (int cand = 4; cand >= 1; cand /= 2) {
+        const size_t ptiles = e->n_pad / ((size_t)kWG * cand);
+        size_t sp = (want + ptiles - 1) / ptiles;
+        if (sp > max_splits) sp = max_splits;
+        if (sp < 1) sp = 1;
+        const size_t wgs = ptiles * sp;
+        if (wgs >= 12 * cus) { ppl = cand; splits = sp; best_wgs = wgs; break; }
+        if (wgs > best_wgs) { ppl = cand; splits = sp; best_wgs = wgs; }
+    }
+    const int env_ppl = env_int("ICP_AMD_PPL", 0);
+    if (env_ppl == 1 || env_ppl == 2 || env_ppl == 4) {
+        ppl = env_ppl;
+        const size_t ptiles = e->n_pad / ((size_t)kWG * ppl);
+        splits = (want + ptiles - 1) / ptiles;
+        if (splits > max_splits) splits = max_splits;
+    }
     if (e->opt.q_splits > 0) splits = (size_t)e->opt.q_splits;
     splits = (size_t)env_int("ICP_AMD_QSPLITS", (int)splits);
     if (splits < 1) splits = 1;
     if (splits > tiles) splits = tiles;
     e->ppl = ppl;
     e->q_splits = (int)splits;
+    // an un-seeded search re-learns its running minimum in every split: keep the first iteration coarser
+    e->q_splits_first = (int)(splits > 16 ? 16 : splits);
     int cb = env_int("ICP_AMD_CB", 32);
     if (cb != 8 && cb != 16 && cb != 32) cb = 32;
     e->cb = cb;
@@ -389,10 +402,11 @@ extern "C" int icp_amd_step_search(icp_amd_engine *e)
             RCCHK(time_begin(e, &a, &b));
         }
         const bool seed = e->have_prev && env_int("ICP_AMD_SEED", 1) != 0;
-        HIPCHK(search(e->stream, e->variant, e->ppl, e->cb, e->P, e->n_pad, e->pc, e->Qz, e->m, e->m_pad, e->q_splits,
+        const int splits = seed ? e->q_splits : e->q_splits_first;
+        HIPCHK(search(e->stream, e->variant, e->ppl, e->cb, e->P, e->n_pad, e->pc, e->Qz, e->m, e->m_pad, splits,
                       seed ? e->idx : nullptr, e->keys, e->idxs));
         if (e->opt.kernel_timing) HIPCHK(hipEventRecord(b, e->stream));
-        HIPCHK(merge_cov(e->stream, e->P, e->n, e->n_pad, e->pc, e->Qz, e->m, e->q_splits, e->keys, e->idxs, e->idx, cov_slot));
+        HIPCHK(merge_cov(e->stream, e->P, e->n, e->n_pad, e->pc, e->Qz, e->m, splits, e->keys, e->idxs, e->idx, cov_slot));
         e->have_prev = true;
     }
     return ICP_AMD_OK;
@@ -551,6 +565,132 @@ extern "C" int icp_amd_run(const double *P, size_t n, const double *Q, size_t m,
     }
     if (rc == ICP_AMD_OK) rc = icp_amd_get_source(e, P_out);
     icp_amd_destroy(e);
+    return rc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// multi-registration mode
+// ------------------------------------------------------------------------------------------------
+struct icp_amd_batch {
+    int device = 0;
+    size_t batch = 0, n = 0, m = 0;
+    hipStream_t stream = nullptr;
+    double *P_in = nullptr, *Q_in = nullptr, *P_out = nullptr, *rec = nullptr;
+    uint32_t *idx = nullptr;
+    bool uploaded = false, ran = false;
+};
+
+extern "C" int icp_amd_batch_destroy(icp_amd_batch *b)
+{
+    if (!b) return ICP_AMD_OK;
+    (void)hipSetDevice(b->device);
+    if (b->stream) { (void)hipStreamSynchronize(b->stream); (void)hipStreamDestroy(b->stream); }
+    free_dev(b->P_in); free_dev(b->Q_in); free_dev(b->P_out); free_dev(b->rec); free_dev(b->idx);
+    delete b;
+    return ICP_AMD_OK;
+}
+
+extern "C" int icp_amd_batch_create(icp_amd_batch **out, int device, size_t batch, size_t n, size_t m)
+{
+    if (!out) return fail(ICP_AMD_EINVAL, "icp_amd_batch_create: out is NULL");
+    *out = nullptr;
+    if (batch == 0 || n == 0 || m == 0) return fail(ICP_AMD_EINVAL, "icp_amd_batch_create: empty batch or cloud (batch=%zu n=%zu m=%zu)", batch, n, m);
+    if (n > kBatchMaxN || m > kBatchMaxM || batch > 0x7FFFFFFFu)
+        return fail(ICP_AMD_EINVAL, "batch mode holds one registration per workgroup: n <= %zu, m <= %zu (got n=%zu m=%zu); use icp_amd_run for larger clouds",
+                    kBatchMaxN, kBatchMaxM, n, m);
+    RCCHK(require_device(device));
+    icp_amd_batch *b = new (std::nothrow) icp_amd_batch();
+    if (!b) return fail(ICP_AMD_ENOMEM, "out of host memory");
+    b->device = device; b->batch = batch; b->n = n; b->m = m;
+    hipError_t er = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking);
+    if (er == hipSuccess) er = hipMalloc(&b->P_in, batch * n * 3 * sizeof(double));
+    if (er == hipSuccess) er = hipMalloc(&b->Q_in, batch * m * 3 * sizeof(double));
+    if (er == hipSuccess) er = hipMalloc(&b->P_out, batch * n * 3 * sizeof(double));
+    if (er == hipSuccess) er = hipMalloc(&b->rec, batch * kSolveW * sizeof(double));
+    if (er == hipSuccess) er = hipMalloc(&b->idx, batch * n * sizeof(uint32_t));
+    if (er != hipSuccess) {
+        icp_amd_batch_destroy(b);
+        return fail(er == hipErrorOutOfMemory ? ICP_AMD_ENOMEM : ICP_AMD_EHIP, "icp_amd_batch_create: %s", hipGetErrorString(er));
+    }
+    *out = b;
+    return ICP_AMD_OK;
+}
+
+extern "C" int icp_amd_batch_upload(icp_amd_batch *b, const double *P, const double *Q)
+{
+    if (!b || !P || !Q) return fail(ICP_AMD_EINVAL, "icp_amd_batch_upload: NULL argument");
+    HIPCHK(hipSetDevice(b->device));
+    HIPCHK(hipMemcpyAsync(b->P_in, P, b->batch * b->n * 3 * sizeof(double), hipMemcpyHostToDevice, b->stream));
+    HIPCHK(hipMemcpyAsync(b->Q_in, Q, b->batch * b->m * 3 * sizeof(double), hipMemcpyHostToDevice, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    b->uploaded = true;
+    b->ran = false;
+    return ICP_AMD_OK;
+}
+
+extern "C" int icp_amd_batch_run(icp_amd_batch *b, unsigned iters, int search_variant, double *elapsed_ms)
+{
+    if (!b) return fail(ICP_AMD_EINVAL, "icp_amd_batch_run: NULL handle");
+    if (!b->uploaded) return fail(ICP_AMD_ESTATE, "icp_amd_batch_run: upload the clouds first");
+    HIPCHK(hipSetDevice(b->device));
+    int variant = search_variant == ICP_AMD_SEARCH_EXACT ? kExact : kFma;
+    const char *sv = getenv("ICP_AMD_SEARCH");
+    if (sv && !strcmp(sv, "fma")) variant = kFma;
+    if (sv && !strcmp(sv, "exact")) variant = kExact;
+    hipEvent_t a = nullptr, z = nullptr;
+    if (elapsed_ms) {
+        HIPCHK(hipEventCreate(&a));
+        HIPCHK(hipEventCreate(&z));
+        HIPCHK(hipEventRecord(a, b->stream));
+    }
+    hipError_t er = batch_icp(b->stream, variant, b->P_in, b->Q_in, b->batch, b->n, b->m, iters, b->P_out, b->rec, b->idx);
+    if (er == hipSuccess && elapsed_ms) {
+        er = hipEventRecord(z, b->stream);
+        if (er == hipSuccess) er = hipEventSynchronize(z);
+        float ms = 0;
+        if (er == hipSuccess) er = hipEventElapsedTime(&ms, a, z);
+        *elapsed_ms = ms;
+    }
+    if (a) (void)hipEventDestroy(a);
+    if (z) (void)hipEventDestroy(z);
+    HIPCHK(er);
+    b->ran = true;
+    return ICP_AMD_OK;
+}
+
+extern "C" int icp_amd_batch_download(icp_amd_batch *b, double *P_out, double *R, double *t, double *cov, int32_t *idx, double *rms)
+{
+    if (!b) return fail(ICP_AMD_EINVAL, "icp_amd_batch_download: NULL handle");
+    if (!b->ran) return fail(ICP_AMD_ESTATE, "icp_amd_batch_download: nothing has run");
+    HIPCHK(hipSetDevice(b->device));
+    std::vector<double> rec;
+    if (P_out) HIPCHK(hipMemcpyAsync(P_out, b->P_out, b->batch * b->n * 3 * sizeof(double), hipMemcpyDeviceToHost, b->stream));
+    if (idx) HIPCHK(hipMemcpyAsync(idx, b->idx, b->batch * b->n * sizeof(uint32_t), hipMemcpyDeviceToHost, b->stream));
+    if (R || t || cov || rms) {
+        rec.resize(b->batch * kSolveW);
+        HIPCHK(hipMemcpyAsync(rec.data(), b->rec, rec.size() * sizeof(double), hipMemcpyDeviceToHost, b->stream));
+    }
+    HIPCHK(hipStreamSynchronize(b->stream));
+    for (size_t k = 0; k < b->batch && !rec.empty(); ++k) {
+        const double *r = rec.data() + k * kSolveW;
+        if (cov) memcpy(cov + 9 * k, r, 9 * sizeof(double));
+        if (R) memcpy(R + 9 * k, r + 12, 9 * sizeof(double));
+        if (t) memcpy(t + 3 * k, r + 21, 3 * sizeof(double));
+        if (rms) rms[k] = r[24];
+    }
+    return ICP_AMD_OK;
+}
+
+extern "C" int icp_amd_run_batch(const double *P, const double *Q, size_t batch, size_t n, size_t m, unsigned iters, double *P_out,
+                                 double *R, double *t, int32_t *idx, double *rms)
+{
+    if (!P || !Q || !P_out) return fail(ICP_AMD_EINVAL, "icp_amd_run_batch: NULL argument");
+    icp_amd_batch *b = nullptr;
+    RCCHK(icp_amd_batch_create(&b, env_int("ICP_AMD_DEVICE", 0), batch, n, m));
+    int rc = icp_amd_batch_upload(b, P, Q);
+    if (rc == ICP_AMD_OK) rc = icp_amd_batch_run(b, iters, ICP_AMD_SEARCH_AUTO, nullptr);
+    if (rc == ICP_AMD_OK) rc = icp_amd_batch_download(b, P_out, R, t, nullptr, idx, rms);
+    icp_amd_batch_destroy(b);
     return rc;
 }
 

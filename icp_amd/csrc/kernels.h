@@ -54,6 +54,15 @@ hipError_t solve(hipStream_t s, const double *partial, size_t count, const doubl
 // P <- P R^T + t (R, t read from the solve record) and per-chunk sums of the new P.
 hipError_t apply(hipStream_t s, Soa3 P, size_t n, const double *solve_rec, double *cen_partial);
 
+// Multi-registration mode: `batch` independent registrations of n x m points, one workgroup each, all iterations
+// on-chip.  P_in [batch][n][3], Q_in [batch][m][3] row-major; P_out same shape; rec_out [batch][kSolveW] = the
+// last iteration's solve record; idx_out [batch][n] (both optional).  n <= kBatchMaxN, m <= kBatchMaxM.
+constexpr size_t kBatchMaxN = 2048;
+constexpr size_t kBatchMaxM = 4096;
+size_t batch_lds_bytes(size_t m);
+hipError_t batch_icp(hipStream_t s, int variant, const double *P_in, const double *Q_in, size_t batch, size_t n, size_t m,
+                     unsigned iters, double *P_out, double *rec_out, uint32_t *idx_out);
+
 // test hook: key[i] = sqrt(sqrt(d2[i])) computed on the device
 hipError_t fourth_root(hipStream_t s, const double *d2, size_t n, double *key);
 

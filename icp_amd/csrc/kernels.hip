@@ -186,6 +186,77 @@ __device__ __forceinline__ void rescan_block(double ax, double ay, double az, co
 // candidate, so seeding (bk, bj) with it changes nothing in the result (the order on (key, index) is
 // total) -- it only makes the running minimum tight from the first target on, so that almost no block
 // takes the slow path, in every target split.
+// Per-lane search state for PPL source points.
+template <int PPL>
+struct LaneSearch {
+    double ax[PPL], ay[PPL], az[PPL];  // centred source points: P = P_copy - P_center (src/cpu/icp.cpp:208)
+    double m_[PPL];                    // running minimum in filter space, starts each block at thr
+    double thr[PPL];                   // filter-space image of bd
+    double bd[PPL], bk[PPL];
+    uint32_t bj[PPL];
+};
+
+template <int MODE>
+__device__ __forceinline__ double filter_threshold(double bd)
+{
+    // fused and un-fused d^2 agree within (1+u)^6: any target with exact d^2 < bd has a fused d^2 below
+    // bd*(1+2^-49) (+ a subnormal-range guard)
+    return (MODE == kFma) ? __builtin_fma(bd, 1.0 + 0x1p-49, 1e-300) : bd;
+}
+
+// Start of a scan for slot s: nothing seen, or seeded with target js (coordinates sx,sy,sz; js >= m means none).
+template <int PPL, int MODE>
+__device__ __forceinline__ void lane_init(LaneSearch<PPL> &L, int s, bool seeded, uint32_t js, double sx, double sy, double sz)
+{
+    L.bd[s] = INFINITY;  // oracle: min_dist = DBL_MAX on the key, i.e. any finite d^2 is accepted
+    L.bk[s] = INFINITY;
+    L.bj[s] = 0xFFFFFFFFu;
+    if (seeded) {
+        const double d = d2_exact(L.ax[s], L.ay[s], L.az[s], sx, sy, sz);
+        if (d < INFINITY) {
+            L.bk[s] = key_of(d);
+            L.bj[s] = js;
+            // targets with the same key and a lower index must still get through: their d^2 lies within a
+            // few ulp of d (the fourth root merges at most ~8 neighbouring doubles), far inside this margin
+            L.bd[s] = __builtin_fma(d, 1.0 + 0x1p-48, 1e-300);
+        }
+    }
+    L.thr[s] = filter_threshold<MODE>(L.bd[s]);
+    L.m_[s] = __builtin_fmin(L.thr[s], INFINITY);
+}
+
+// Scan `count` (multiple of CB) targets held in LDS as SoA; jbase = global index of target 0 of the tile.
+template <int PPL, int MODE, int CB>
+__device__ __forceinline__ void scan_tile(LaneSearch<PPL> &L, const double *sx, const double *sy, const double *sz, int count,
+                                          unsigned jbase)
+{
+    for (int j0 = 0; j0 < count; j0 += CB) {
+#pragma unroll
+        for (int u = 0; u < CB; ++u) {
+            const double tx = sx[j0 + u], ty = sy[j0 + u], tz = sz[j0 + u];
+#pragma unroll
+            for (int s = 0; s < PPL; ++s) {
+                const double d = (MODE == kFma) ? d2_fused(L.ax[s], L.ay[s], L.az[s], tx, ty, tz)
+                                                : d2_exact(L.ax[s], L.ay[s], L.az[s], tx, ty, tz);
+                L.m_[s] = __builtin_fmin(L.m_[s], d);
+            }
+        }
+        bool ev = false;
+#pragma unroll
+        for (int s = 0; s < PPL; ++s) ev |= (L.m_[s] < L.thr[s]);
+        if (ev) {
+#pragma unroll
+            for (int s = 0; s < PPL; ++s) {
+                if (L.m_[s] < L.thr[s]) {
+                    rescan_block<CB>(L.ax[s], L.ay[s], L.az[s], sx, sy, sz, j0, jbase + (unsigned)j0, L.bd[s], L.bk[s], L.bj[s]);
+                    L.thr[s] = filter_threshold<MODE>(L.bd[s]);
+                    L.m_[s] = __builtin_fmin(L.thr[s], INFINITY);
+                }
+            }
+        }
+    }
+}
+
 template <int PPL, int MODE, int CB>
 __global__ __launch_bounds__(kWG) void search_kernel(const double *__restrict__ px, const double *__restrict__ py,
                                                      const double *__restrict__ pz, const double *__restrict__ pc,
@@ -199,34 +270,23 @@ __global__ __launch_bounds__(kWG) void search_kernel(const double *__restrict__ 
     const unsigned base = blockIdx.x * (kWG * PPL) + tid;
     const double c0 = pc[0], c1 = pc[1], c2 = pc[2];
 
-    double ax[PPL], ay[PPL], az[PPL];  // centred source points: P = P_copy - P_center (src/cpu/icp.cpp:208)
-    double m_[PPL];                    // running minimum in filter space, starts each block at thr
-    double thr[PPL];                   // filter-space image of bd
-    double bd[PPL], bk[PPL];
-    uint32_t bj[PPL];
+    LaneSearch<PPL> L;
 #pragma unroll
     for (int s = 0; s < PPL; ++s) {
-        ax[s] = px[base + s * kWG] - c0;
-        ay[s] = py[base + s * kWG] - c1;
-        az[s] = pz[base + s * kWG] - c2;
-        bd[s] = INFINITY;  // oracle: min_dist = DBL_MAX on the key, i.e. any finite d^2 is accepted
-        bk[s] = INFINITY;
-        bj[s] = 0xFFFFFFFFu;
+        L.ax[s] = px[base + s * kWG] - c0;
+        L.ay[s] = py[base + s * kWG] - c1;
+        L.az[s] = pz[base + s * kWG] - c2;
+        uint32_t js = 0xFFFFFFFFu;
+        double sx = 0, sy = 0, sz = 0;
         if (idx_prev) {
-            const uint32_t js = idx_prev[base + s * kWG];
+            js = idx_prev[base + s * kWG];
             if (js < m) {
-                const double d = d2_exact(ax[s], ay[s], az[s], qx[js], qy[js], qz[js]);
-                if (d < INFINITY) {
-                    bk[s] = key_of(d);
-                    bj[s] = js;
-                    // targets with the same key and a lower index must still get through: their d^2 lies within a
-                    // few ulp of d (the fourth root merges at most ~8 neighbouring doubles), far inside this margin
-                    bd[s] = __builtin_fma(d, 1.0 + 0x1p-48, 1e-300);
-                }
+                sx = qx[js];
+                sy = qy[js];
+                sz = qz[js];
             }
         }
-        thr[s] = (MODE == kFma) ? __builtin_fma(bd[s], 1.0 + 0x1p-49, 1e-300) : bd[s];
-        m_[s] = __builtin_fmin(thr[s], INFINITY);
+        lane_init<PPL, MODE>(L, s, js < m, js, sx, sy, sz);
     }
 
     const unsigned q0 = blockIdx.y * q_per_split;
@@ -239,39 +299,13 @@ __global__ __launch_bounds__(kWG) void search_kernel(const double *__restrict__ 
             sq[2][k] = qz[t0 + k];
         }
         __syncthreads();
-        for (int j0 = 0; j0 < kTileQ; j0 += CB) {
-#pragma unroll
-            for (int u = 0; u < CB; ++u) {
-                const double tx = sq[0][j0 + u], ty = sq[1][j0 + u], tz = sq[2][j0 + u];
-#pragma unroll
-                for (int s = 0; s < PPL; ++s) {
-                    const double d = (MODE == kFma) ? d2_fused(ax[s], ay[s], az[s], tx, ty, tz)
-                                                    : d2_exact(ax[s], ay[s], az[s], tx, ty, tz);
-                    m_[s] = __builtin_fmin(m_[s], d);
-                }
-            }
-            bool ev = false;
-#pragma unroll
-            for (int s = 0; s < PPL; ++s) ev |= (m_[s] < thr[s]);
-            if (ev) {
-#pragma unroll
-                for (int s = 0; s < PPL; ++s) {
-                    if (m_[s] < thr[s]) {
-                        rescan_block<CB>(ax[s], ay[s], az[s], sq[0], sq[1], sq[2], j0, t0 + (unsigned)j0, bd[s], bk[s], bj[s]);
-                        // fused and un-fused d^2 agree within (1+u)^6: any target with exact d^2 < bd has a
-                        // fused d^2 below bd*(1+2^-49) (+ a subnormal-range guard)
-                        thr[s] = (MODE == kFma) ? __builtin_fma(bd[s], 1.0 + 0x1p-49, 1e-300) : bd[s];
-                        m_[s] = __builtin_fmin(thr[s], INFINITY);
-                    }
-                }
-            }
-        }
+        scan_tile<PPL, MODE, CB>(L, sq[0], sq[1], sq[2], kTileQ, t0);
     }
     const size_t o = (size_t)blockIdx.y * n_pad + base;
 #pragma unroll
     for (int s = 0; s < PPL; ++s) {
-        out_key[o + s * kWG] = bk[s];
-        out_idx[o + s * kWG] = bj[s];
+        out_key[o + s * kWG] = L.bk[s];
+        out_idx[o + s * kWG] = L.bj[s];
     }
 }
 
@@ -340,7 +374,7 @@ __device__ void svd3(const double *A, double *U, double *S, double *VT)
 {
     double a[9], v[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
     for (int k = 0; k < 9; ++k) a[k] = A[k];
-    for (int sweep = 0; sweep < 60; ++sweep) {
+    for (int sweep = 0; sweep < 30; ++sweep) {
         bool rotated = false;
         for (int k = 0; k < 3; ++k) {
             const int p = (k == 2) ? 1 : 0, q = (k == 0) ? 1 : 2;
@@ -350,7 +384,7 @@ __device__ void svd3(const double *A, double *U, double *S, double *VT)
                 beta += a[i * 3 + q] * a[i * 3 + q];
                 gamma += a[i * 3 + p] * a[i * 3 + q];
             }
-            if (gamma == 0.0 || fabs(gamma) <= 1e-17 * sqrt(alpha * beta)) continue;
+            if (gamma == 0.0 || fabs(gamma) <= 4.5e-16 * sqrt(alpha * beta)) continue;
             rotated = true;
             const double zeta = (beta - alpha) / (2.0 * gamma);
             const double tt = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
@@ -419,6 +453,8 @@ __device__ void svd3(const double *A, double *U, double *S, double *VT)
         }
 }
 
+__device__ void solve_record(const double *tot, const double *pc, const double *qc, double n_global, double *out);
+
 __global__ __launch_bounds__(kWG) void solve_kernel(const double *__restrict__ partial, size_t count,
                                                     const double *__restrict__ pc, const double *__restrict__ qc,
                                                     double n_global, double *__restrict__ out)
@@ -429,6 +465,12 @@ __global__ __launch_bounds__(kWG) void solve_kernel(const double *__restrict__ p
     if (threadIdx.x < kCovW) tot[threadIdx.x] = acc;
     __syncthreads();
     if (threadIdx.x != 0) return;
+    solve_record(tot, pc, qc, n_global, out);
+}
+
+// One lane: cov -> SVD -> R, t; writes the 28-double record (layout in kernels.h).
+__device__ void solve_record(const double *tot, const double *pc, const double *qc, double n_global, double *out)
+{
     double cov[9], U[9], S[3], VT[9], R[9], t[3];
     for (int k = 0; k < 9; ++k) cov[k] = tot[k];
     svd3(cov, U, S, VT);
@@ -485,6 +527,244 @@ __global__ __launch_bounds__(kWG) void apply_kernel(double *__restrict__ px, dou
     }
     const double tot = block_sum<3>(acc, smem);
     if (threadIdx.x < 3) cen_partial[(size_t)blockIdx.x * kCenW + threadIdx.x] = tot;
+}
+
+// ------------------------------------------------------------------------------------------------
+// small-target search (whole target cloud in LDS, <= 4096 points): index carried in the mantissa
+// ------------------------------------------------------------------------------------------------
+// With only ~1000 targets and 256 source points per wave, "some lane's minimum moved" is true in every block,
+// so the event scheme of search_kernel degenerates.  Here the fast path needs no events at all: the low 12
+// mantissa bits of every (fused) d^2 are replaced by the target index (one v_and_or_b32), after which a plain
+// v_min_f64 tracks value and index together (lowest index wins among equal truncated values), and a
+// v_max/v_min pair tracks the runner-up.  If the runner-up is more than 2^-38 (relative) above the minimum, no
+// other target can have an oracle key <= the winner's (truncation 2^-40, fusion 6u, and a key gap of 2^-42 is far
+// above the rounding of the two square roots), so the embedded index is the oracle's answer.  Otherwise -- true
+// near-ties, duplicates, lattice data -- that source point is re-scanned exactly.
+constexpr double kSmallPad = 1e150;            // pad target coordinate: d^2 ~ 3e300, finite (a NaN would poison the runner-up)
+constexpr unsigned kSmallIdxMask = 0xFFFFF000u;
+
+template <int MODE>
+__device__ __forceinline__ double packed_d2(double ax, double ay, double az, double tx, double ty, double tz, unsigned j)
+{
+    const double d = (MODE == kFma) ? d2_fused(ax, ay, az, tx, ty, tz) : d2_exact(ax, ay, az, tx, ty, tz);
+    unsigned long long b = (unsigned long long)__double_as_longlong(d);
+    unsigned lo;
+    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(lo) : "v"((unsigned)b), "s"(kSmallIdxMask), "v"(j));   // (lo & mask) | j
+    b = (b & 0xFFFFFFFF00000000ull) | lo;
+    return __longlong_as_double((long long)b);
+}
+
+// v_min_f64 / v_max_f64 on values known to be finite, non-NaN doubles with integer-edited mantissas: spelled as
+// instructions so that the compiler does not add a canonicalising v_max_f64 x,x in front of each of them.
+__device__ __forceinline__ double vmin64(double a, double b)
+{
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ double vmax64(double a, double b)
+{
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+// Exact (oracle-order) scan of all m targets for one source point: first minimum of sqrt(sqrt(d^2)).
+__device__ __noinline__ uint32_t exact_scan_small(double ax, double ay, double az, const double *sx, const double *sy, const double *sz,
+                                                  unsigned m)
+{
+    double bd = INFINITY, bk = INFINITY;
+    uint32_t bj = 0xFFFFFFFFu;
+    for (unsigned j = 0; j < m; ++j) {
+        const double d = d2_exact(ax, ay, az, sx[j], sy[j], sz[j]);
+        if (d < bd) {
+            bd = d;
+            const double key = key_of(d);
+            if (key < bk) {
+                bk = key;
+                bj = j;
+            }
+        }
+    }
+    return bj;
+}
+
+template <int PPL, int MODE>
+__device__ __forceinline__ void scan_small(const double (&ax)[PPL], const double (&ay)[PPL], const double (&az)[PPL], const double *sx,
+                                           const double *sy, const double *sz, unsigned m, unsigned m_pad, uint32_t (&bj)[PPL])
+{
+    double m1[PPL], m2[PPL];
+#pragma unroll
+    for (int s = 0; s < PPL; ++s) m1[s] = m2[s] = INFINITY;
+    for (unsigned j0 = 0; j0 < m_pad; j0 += 8) {
+#pragma unroll
+        for (unsigned u = 0; u < 8; ++u) {
+            const double tx = sx[j0 + u], ty = sy[j0 + u], tz = sz[j0 + u];
+#pragma unroll
+            for (int s = 0; s < PPL; ++s) {
+                const double t = packed_d2<MODE>(ax[s], ay[s], az[s], tx, ty, tz, j0 + u);
+                m2[s] = vmin64(m2[s], vmax64(m1[s], t));
+                m1[s] = vmin64(m1[s], t);
+            }
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < PPL; ++s) {
+        const unsigned j = (unsigned)__double_as_longlong(m1[s]) & ~kSmallIdxMask;
+        const bool unique = (m2[s] > m1[s] * (1.0 + 0x1p-38)) && (m1[s] > 1e-290) && (m1[s] < 1e290) && (j < m);
+        bj[s] = j;
+        if (!unique) bj[s] = exact_scan_small(ax[s], ay[s], az[s], sx, sy, sz, m);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// multi-registration mode: one workgroup = one whole registration, every iteration on-chip
+// ------------------------------------------------------------------------------------------------
+// BASELINE config 5 (thousands of small independent registrations).  The centred target lives in LDS (SoA),
+// the source points in registers (PPL per lane), and the loop centroid -> search (scan_small) -> covariance ->
+// solve -> apply runs `iters` times without touching HBM.  All reductions have the shape the engine uses (1024-row chunks:
+// 4 rows per lane in order, wave butterfly, waves in order; chunks in order), so a registration computed here is
+// bit-identical to the same registration run through icp_amd_run.
+template <int PPL, int MODE>
+__global__ __launch_bounds__(kWG) void batch_icp_kernel(const double *__restrict__ P_in, const double *__restrict__ Q_in, unsigned n,
+                                                        unsigned m, unsigned m_pad, unsigned iters, double *__restrict__ P_out,
+                                                        double *__restrict__ rec_out, uint32_t *__restrict__ idx_out)
+{
+    extern __shared__ double lds[];
+    double *sx = lds, *sy = lds + m_pad, *sz = lds + 2 * (size_t)m_pad;
+    double *red = lds + 3 * (size_t)m_pad;  // 4*12: scratch of block_sum
+    double *bc = red + 48;                  // [0..2] Pc, [4..15] cov sums, [16..18] Qc, [20..47] solve record
+    constexpr int NCH = PPL / 4;            // 1024-row chunks covered by the PPL*256 slots
+    const unsigned tid = threadIdx.x;
+    const double *Pb = P_in + (size_t)blockIdx.x * n * 3;
+    const double *Qb = Q_in + (size_t)blockIdx.x * m * 3;
+
+    // Q_center = Q.mean(0); Q -= Q_center (src/cpu/icp.cpp:197-198)
+    double tq = 0.0;
+    for (unsigned c0 = 0; c0 < m; c0 += kChunk) {
+        double acc[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const unsigned i = c0 + k * kWG + tid;
+            if (i < m) {
+                acc[0] += Qb[(size_t)i * 3 + 0];
+                acc[1] += Qb[(size_t)i * 3 + 1];
+                acc[2] += Qb[(size_t)i * 3 + 2];
+            }
+        }
+        __syncthreads();
+        const double t = block_sum<3>(acc, red);
+        if (tid < 3) tq += t;
+    }
+    if (tid < 3) bc[16 + tid] = tq / (double)m;
+    __syncthreads();
+    const double qc0 = bc[16], qc1 = bc[17], qc2 = bc[18];
+    for (unsigned j = tid; j < m_pad; j += kWG) {
+        const bool in = j < m;
+        sx[j] = in ? Qb[(size_t)j * 3 + 0] - qc0 : kSmallPad;
+        sy[j] = in ? Qb[(size_t)j * 3 + 1] - qc1 : kSmallPad;
+        sz[j] = in ? Qb[(size_t)j * 3 + 2] - qc2 : kSmallPad;
+    }
+    double px[PPL], py[PPL], pz[PPL];
+    uint32_t bj[PPL];
+#pragma unroll
+    for (int s = 0; s < PPL; ++s) {
+        const unsigned i = s * kWG + tid;
+        const bool in = i < n;
+        px[s] = in ? Pb[(size_t)i * 3 + 0] : 0.0;
+        py[s] = in ? Pb[(size_t)i * 3 + 1] : 0.0;
+        pz[s] = in ? Pb[(size_t)i * 3 + 2] : 0.0;
+        bj[s] = 0xFFFFFFFFu;
+    }
+    __syncthreads();
+
+    for (unsigned it = 0; it < iters; ++it) {
+        // P_center = P_copy.mean(0) (src/cpu/icp.cpp:206)
+        double tc = 0.0;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            double acc[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int s = c * 4 + k;
+                if (s * kWG + tid < n) {
+                    acc[0] += px[s];
+                    acc[1] += py[s];
+                    acc[2] += pz[s];
+                }
+            }
+            __syncthreads();
+            const double t = block_sum<3>(acc, red);
+            if (tid < 3) tc += t;
+        }
+        if (tid < 3) bc[tid] = tc / (double)n;
+        __syncthreads();
+        const double c0 = bc[0], c1 = bc[1], c2 = bc[2];
+
+        // correspondences (src/cpu/icp.cpp:210)
+        double ax[PPL], ay[PPL], az[PPL];
+#pragma unroll
+        for (int s = 0; s < PPL; ++s) {
+            ax[s] = px[s] - c0;
+            ay[s] = py[s] - c1;
+            az[s] = pz[s] - c2;
+        }
+        scan_small<PPL, MODE>(ax, ay, az, sx, sy, sz, m, m_pad, bj);
+
+        // cross-covariance (src/cpu/icp.cpp:214)
+        double tv = 0.0;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            double acc[kCovW];
+#pragma unroll
+            for (int k = 0; k < kCovW; ++k) acc[k] = 0.0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int s = c * 4 + k;
+                const uint32_t j = bj[s];
+                if (s * kWG + tid < n && j < m) {
+                    const double p0 = ax[s], p1 = ay[s], p2 = az[s];
+                    const double q0 = sx[j], q1 = sy[j], q2 = sz[j];
+                    acc[0] += q0 * p0; acc[1] += q0 * p1; acc[2] += q0 * p2;
+                    acc[3] += q1 * p0; acc[4] += q1 * p1; acc[5] += q1 * p2;
+                    acc[6] += q2 * p0; acc[7] += q2 * p1; acc[8] += q2 * p2;
+                    acc[9] += d2_exact(p0, p1, p2, q0, q1, q2);
+                }
+            }
+            __syncthreads();
+            const double t = block_sum<kCovW>(acc, red);
+            if (tid < kCovW) tv += t;
+        }
+        if (tid < kCovW) bc[4 + tid] = tv;
+        __syncthreads();
+        // svd, R, t (src/cpu/icp.cpp:218-223)
+        if (tid == 0) solve_record(bc + 4, bc, bc + 16, (double)n, bc + 20);
+        __syncthreads();
+        // P_copy = P_copy.dot(R.transpose()) + t (src/cpu/icp.cpp:225)
+        const double *R = bc + 20 + 12, *t = bc + 20 + 21;
+        const double r00 = R[0], r01 = R[1], r02 = R[2], r10 = R[3], r11 = R[4], r12 = R[5], r20 = R[6], r21 = R[7], r22 = R[8];
+        const double t0 = t[0], t1 = t[1], t2 = t[2];
+#pragma unroll
+        for (int s = 0; s < PPL; ++s) {
+            const double x = px[s], y = py[s], z = pz[s];
+            px[s] = ((x * r00 + y * r01) + z * r02) + t0;
+            py[s] = ((x * r10 + y * r11) + z * r12) + t1;
+            pz[s] = ((x * r20 + y * r21) + z * r22) + t2;
+        }
+        __syncthreads();  // bc is rewritten by the next iteration
+    }
+#pragma unroll
+    for (int s = 0; s < PPL; ++s) {
+        const unsigned i = s * kWG + tid;
+        if (i < n) {
+            double *o = P_out + ((size_t)blockIdx.x * n + i) * 3;
+            o[0] = px[s];
+            o[1] = py[s];
+            o[2] = pz[s];
+            if (idx_out) idx_out[(size_t)blockIdx.x * n + i] = bj[s];
+        }
+    }
+    if (rec_out && tid < kSolveW) rec_out[(size_t)blockIdx.x * kSolveW + tid] = iters ? bc[20 + tid] : 0.0;
 }
 
 __global__ __launch_bounds__(kWG) void fourth_root_kernel(const double *__restrict__ d2, size_t n, double *__restrict__ key)
@@ -584,6 +864,34 @@ hipError_t apply(hipStream_t s, Soa3 P, size_t n, const double *solve_rec, doubl
     if (n == 0) return hipSuccess;
     apply_kernel<<<blocks_for(n, kChunk), kWG, 0, s>>>(P.x, P.y, P.z, n, solve_rec, cen_partial);
     return hipGetLastError();
+}
+
+size_t batch_lds_bytes(size_t m) { return (3 * ((m + 31) / 32 * 32) + 48 + 48) * sizeof(double); }
+
+template <int PPL, int MODE>
+static hipError_t batch_launch(hipStream_t s, const double *P_in, const double *Q_in, size_t batch, size_t n, size_t m, unsigned iters,
+                               double *P_out, double *rec_out, uint32_t *idx_out)
+{
+    const size_t lds = batch_lds_bytes(m);
+    auto kern = batch_icp_kernel<PPL, MODE>;
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    kern<<<(unsigned)batch, kWG, lds, s>>>(P_in, Q_in, (unsigned)n, (unsigned)m, (unsigned)((m + 31) / 32 * 32), iters, P_out, rec_out,
+                                           idx_out);
+    return hipGetLastError();
+}
+
+hipError_t batch_icp(hipStream_t s, int variant, const double *P_in, const double *Q_in, size_t batch, size_t n, size_t m,
+                     unsigned iters, double *P_out, double *rec_out, uint32_t *idx_out)
+{
+    if (batch == 0 || n == 0 || m == 0 || n > kBatchMaxN || m > kBatchMaxM || batch > 0x7FFFFFFFu) return hipErrorInvalidValue;
+    if (n <= 1024)
+        return variant == kFma ? batch_launch<4, kFma>(s, P_in, Q_in, batch, n, m, iters, P_out, rec_out, idx_out)
+                               : batch_launch<4, kExact>(s, P_in, Q_in, batch, n, m, iters, P_out, rec_out, idx_out);
+    return variant == kFma ? batch_launch<8, kFma>(s, P_in, Q_in, batch, n, m, iters, P_out, rec_out, idx_out)
+                           : batch_launch<8, kExact>(s, P_in, Q_in, batch, n, m, iters, P_out, rec_out, idx_out);
 }
 
 hipError_t fourth_root(hipStream_t s, const double *d2, size_t n, double *key)

@@ -120,6 +120,23 @@ int icp_amd_kernel_ms(icp_amd_engine *e, double *search_avg_ms, double *search_t
 /* Launch geometry chosen for the search kernel (for reports). */
 int icp_amd_search_geometry(icp_amd_engine *e, int *points_per_lane, int *q_splits, int *workgroups, int *variant);
 
+/* ---- multi-registration mode (BASELINE config 5: thousands of small independent registrations).
+ *      No counterpart in the reference: its `-batch` flag strip-mines ONE registration 16 source rows at a time
+ *      (src/libgpuicp/batchcovs.cu:28-75).  Here a batch is `batch` independent (P_b, Q_b) pairs of n x 3 and m x 3
+ *      points, concatenated; each runs `iters` iterations inside one workgroup without leaving the chip, and its
+ *      result is bit-identical to icp_amd_run on the same pair.  Limits: n <= 2048, m <= 4096. */
+typedef struct icp_amd_batch icp_amd_batch;
+int icp_amd_batch_create(icp_amd_batch **out, int device, size_t batch, size_t n, size_t m);
+int icp_amd_batch_upload(icp_amd_batch *b, const double *P /* batch*n*3 */, const double *Q /* batch*m*3 */);
+/* Runs `iters` iterations from the uploaded clouds (every call starts again from them). elapsed_ms optional. */
+int icp_amd_batch_run(icp_amd_batch *b, unsigned iters, int search, double *elapsed_ms);
+/* Any pointer may be NULL. R (batch*9), t (batch*3), cov (batch*9), rms (batch): last iteration's. idx: batch*n. */
+int icp_amd_batch_download(icp_amd_batch *b, double *P_out, double *R, double *t, double *cov, int32_t *idx, double *rms);
+int icp_amd_batch_destroy(icp_amd_batch *b);
+/* One-shot convenience over the five calls above. */
+int icp_amd_run_batch(const double *P, const double *Q, size_t batch, size_t n, size_t m, unsigned iters,
+                      double *P_out, double *R, double *t, int32_t *idx, double *rms);
+
 /* ---- stage level, host pointers in and out, computed on the device with the engine's kernels.
  *      These mirror the reference's kernel-wrapper level and exist for parity tests. */
 /* get_array_correspondences_optimized (include/libgpuicp/corresp_optimized.cuh:23-24) with the centring of

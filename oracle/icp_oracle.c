@@ -102,7 +102,7 @@ void oracle_svd3(const double Ain[9], double U[9], double S[3], double VT[9])
             v[i][j] = (i == j) ? 1.0 : 0.0;
         }
     static const int pr[3][2] = {{0, 1}, {0, 2}, {1, 2}};
-    for (int sweep = 0; sweep < 60; ++sweep) {
+    for (int sweep = 0; sweep < 30; ++sweep) {
         int rotated = 0;
         for (int k = 0; k < 3; ++k) {
             int p = pr[k][0], q = pr[k][1];
@@ -112,7 +112,7 @@ void oracle_svd3(const double Ain[9], double U[9], double S[3], double VT[9])
                 beta += a[i][q] * a[i][q];
                 gamma += a[i][p] * a[i][q];
             }
-            if (gamma == 0.0 || fabs(gamma) <= 1e-17 * sqrt(alpha * beta))
+            if (gamma == 0.0 || fabs(gamma) <= 4.5e-16 * sqrt(alpha * beta))
                 continue;
             rotated = 1;
             double zeta = (beta - alpha) / (2.0 * gamma);

@@ -1,0 +1,61 @@
+"""GPU: multi-registration mode (BASELINE config 5).  Every registration of a batch must equal the same pair run
+alone through icp_amd_run, bit for bit, and match the oracle / golden vectors at the parity bar."""
+import numpy as np
+import pytest
+
+import icp_amd
+from conftest import golden, relerr
+from icp_amd import synth
+from oracle import pyoracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("batch,n,m,iters", [(12, 1000, 1000, 6), (5, 700, 900, 4), (3, 1500, 3000, 3), (4, 64, 33, 3), (2, 2048, 4096, 2)])
+def test_batch_equals_single_runs(batch, n, m, iters):
+    Ps, Qs = [], []
+    for b in range(batch):
+        P, Q = synth.make_pair(n, max(n, m), seed=1000 + 7 * b, angle=0.05 + 0.01 * b)
+        Ps.append(P)
+        Qs.append(Q[:m] if m < len(Q) else Q)
+    P, Q = np.stack(Ps), np.stack(Qs)
+    out = icp_amd.icp_gpu_batch(P, Q, iters)
+    for b in range(batch):
+        P_one, tr = icp_amd.icp_gpu_optimized(P[b], Q[b], iters, trace=True)
+        assert np.array_equal(out["idx"][b], tr["idx"][-1]), b
+        assert np.array_equal(out["cov"][b], tr["cov"][-1]), b
+        assert np.array_equal(out["R"][b], tr["R"][-1]) and np.array_equal(out["t"][b], tr["t"][-1]), b
+        assert np.array_equal(out["P_out"][b], P_one), b
+        assert out["rms"][b] == tr["rms"][-1]
+    # and against the oracle for the first two registrations
+    for b in range(min(batch, 2)):
+        ref = orc.icp(P[b], Q[b], iters, trace=True, nthreads=4)
+        assert np.array_equal(out["idx"][b], ref["idx"][-1])
+        assert relerr(out["P_out"][b], ref["P_out"]) < 1e-9
+
+
+def test_batch_of_golden_pairs():
+    g1, g2 = golden("syn1k"), golden("syn256")
+    for g in (g1, g2):
+        iters = int(g["iters"])
+        out = icp_amd.icp_gpu_batch(g["P"][None], g["Q"][None], iters)
+        assert np.array_equal(out["idx"][0], g["idx"][-1])
+        assert relerr(out["R"][0], g["R"][-1]) < 1e-9
+        assert relerr(out["P_out"][0], g["P_out"]) < 1e-9
+
+
+def test_batch_variants_and_limits():
+    P, Q = synth.make_batch(6, 500)
+    b = icp_amd.Batch(6, 500, 500)
+    b.upload(P, Q)
+    b.run(5, search="exact")
+    a = b.download()
+    ms = b.run(5, search="fma", timed=True)
+    c = b.download()
+    b.close()
+    assert ms > 0
+    for k in ("P_out", "idx", "R", "cov"):
+        assert np.array_equal(a[k], c[k]), k
+    for shape in ((1, 2049, 100), (1, 100, 4097), (0, 10, 10), (1, 0, 10)):
+        with pytest.raises(icp_amd.IcpAmdError):
+            icp_amd.Batch(*shape)
