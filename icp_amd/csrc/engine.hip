@@ -97,6 +97,10 @@ struct icp_amd_engine {
     double *q_store = nullptr;  // 3 * m_pad
     Soa3 Qz{nullptr, nullptr, nullptr};
     double *qc = nullptr;       // 3
+    void *qrec = nullptr;       // m_pad 16-byte fp32 records for the f32 pre-filter
+    unsigned long long *qmax2_dev = nullptr;
+    double qmax = 0.0;          // sqrt(max |q|^2) of the centred target
+    bool f32_ok = false;        // the fp32 error bound is meaningful for this target's range
 
     // source (local rows)
     size_t n = 0, n_pad = 0, n_global = 0;
@@ -177,7 +181,7 @@ extern "C" int icp_amd_destroy(icp_amd_engine *e)
     (void)hipSetDevice(e->opt.device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     for (hipEvent_t ev : e->ev) (void)hipEventDestroy(ev);
-    free_dev(e->q_store); free_dev(e->qc); free_dev(e->p_store); free_dev(e->pc); free_dev(e->stage);
+    free_dev(e->q_store); free_dev(e->qc); free_dev(e->qrec); free_dev(e->qmax2_dev); free_dev(e->p_store); free_dev(e->pc); free_dev(e->stage);
     free_dev(e->keys); free_dev(e->idxs); free_dev(e->idx); free_dev(e->rec);
     if (e->own_part) { free_dev(e->cov_part); free_dev(e->cen_part); }
     if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
@@ -204,12 +208,14 @@ extern "C" int icp_amd_set_target(icp_amd_engine *e, const double *Q, size_t m)
     if (m == 0) return fail(ICP_AMD_EINVAL, "target cloud is empty");
     if (m > kMaxRows) return fail(ICP_AMD_EINVAL, "target cloud too large (%zu rows, limit %zu)", m, kMaxRows);
     HIPCHK(hipSetDevice(e->opt.device));
-    const size_t m_pad = round_up(m, kTileQ);
+    const size_t m_pad = round_up(m, kPadRows);
     if (m_pad != e->m_pad) {
-        free_dev(e->q_store);
-        e->q_store = nullptr;
+        free_dev(e->q_store); free_dev(e->qrec);
+        e->q_store = nullptr; e->qrec = nullptr;
         e->m_pad = 0;
         HIPCHK(hipMalloc(&e->q_store, 3 * m_pad * sizeof(double)));
+        HIPCHK(hipMalloc(&e->qrec, 16 * m_pad));
+        if (!e->qmax2_dev) HIPCHK(hipMalloc(&e->qmax2_dev, sizeof(unsigned long long)));
         e->m_pad = m_pad;
         e->Qz = Soa3{e->q_store, e->q_store + m_pad, e->q_store + 2 * m_pad};
     }
@@ -224,9 +230,16 @@ extern "C" int icp_amd_set_target(icp_amd_engine *e, const double *Q, size_t m)
     if (er == hipSuccess) er = finalize_centroid(e->stream, part, chunks, (double)m, e->qc);
     if (er == hipSuccess)
         er = aos_to_soa(e->stream, e->stage, m, m_pad, e->qc, std::numeric_limits<double>::infinity(), e->Qz);
+    if (er == hipSuccess) er = build_qrec(e->stream, e->Qz, m, m_pad, e->qrec, e->qmax2_dev);
+    unsigned long long bits = 0;
+    if (er == hipSuccess) er = hipMemcpyAsync(&bits, e->qmax2_dev, sizeof bits, hipMemcpyDeviceToHost, e->stream);
     if (er == hipSuccess) er = hipStreamSynchronize(e->stream);
     (void)hipFree(part);
     HIPCHK(er);
+    double qmax2;
+    memcpy(&qmax2, &bits, sizeof qmax2);
+    e->f32_ok = (qmax2 == qmax2) && qmax2 > 1e-30 && qmax2 < 1e30;
+    e->qmax = e->f32_ok ? sqrt(qmax2) : 0.0;
     e->have_target = true;
     return ICP_AMD_OK;
 }
@@ -235,26 +248,40 @@ extern "C" int icp_amd_set_target(icp_amd_engine *e, const double *Q, size_t m)
 // cutting the target range into pieces so short that every piece re-learns its running minimum.
 static void choose_geometry(icp_amd_engine *e)
 {
+    // Every variant returns identical indices (each candidate is re-evaluated in the oracle's un-fused fp64 sequence);
+    // they differ in what the fast path costs per pair: EXACT 9.1 fp64 VALU instructions, FMA 7.1 fp64, F32 3.5 fp32.
+    // AUTO = F32, which degrades to FMA when the target's range makes the fp32 bound meaningless.
+    int variant = e->opt.search == ICP_AMD_SEARCH_EXACT ? kExact : e->opt.search == ICP_AMD_SEARCH_FMA ? kFma : kF32;
+    const char *sv = getenv("ICP_AMD_SEARCH");
+    if (sv && !strcmp(sv, "fma")) variant = kFma;
+    if (sv && !strcmp(sv, "exact")) variant = kExact;
+    if (sv && !strcmp(sv, "f32")) variant = kF32;
+    if (variant == kF32 && !e->f32_ok) variant = kFma;
+    e->variant = variant;
+
+    const bool f32 = variant == kF32;
     const size_t cus = (size_t)e->cu_count;
-    const size_t tiles = e->m_pad / kTileQ;
+    const size_t tile = f32 ? 2048 : (size_t)kTileQ;
+    const size_t tiles = e->m_pad / tile;
     const size_t want = 64 * cus;   // measured at 1M x 1M: 8 -> 16 splits (7.8k -> 15.6k workgroups) still gains 0.5 %
-    size_t max_splits = tiles / 4;  // at least four LDS tiles per split
+    size_t max_splits = tiles / (f32 ? 2 : 4);  // a few LDS tiles per split at least
     if (max_splits > 256) max_splits = 256;
     if (max_splits < 1) max_splits = 1;
     // most points per lane (fewest LDS reads per pair) that still yields >= 12 workgroups per CU
-    int ppl = 1;
+    const int ppl_hi = f32 ? 8 : 4, ppl_lo = f32 ? 2 : 1;
+    int ppl = ppl_lo;
     size_t splits = 1, best_wgs = 0;
-    for (int cand = 4; cand >= 1; cand /= 2) {
+    for (int cand = ppl_hi; cand >= ppl_lo; cand /= 2) {
         const size_t ptiles = e->n_pad / ((size_t)kWG * cand);
         size_t sp = (want + ptiles - 1) / ptiles;
         if (sp > max_splits) sp = max_splits;
         if (sp < 1) sp = 1;
         const size_t wgs = ptiles * sp;
-        if (wgs >= 12 * cus) { ppl = cand; splits = sp; best_wgs = wgs; break; }
+        if (wgs >= (f32 ? 8 : 12) * cus) { ppl = cand; splits = sp; best_wgs = wgs; break; }
         if (wgs > best_wgs) { ppl = cand; splits = sp; best_wgs = wgs; }
     }
     const int env_ppl = env_int("ICP_AMD_PPL", 0);
-    if (env_ppl == 1 || env_ppl == 2 || env_ppl == 4) {
+    if ((env_ppl == 1 && !f32) || env_ppl == 2 || env_ppl == 4 || (env_ppl == 8 && f32)) {
         ppl = env_ppl;
         const size_t ptiles = e->n_pad / ((size_t)kWG * ppl);
         splits = (want + ptiles - 1) / ptiles;
@@ -267,17 +294,12 @@ static void choose_geometry(icp_amd_engine *e)
     e->ppl = ppl;
     e->q_splits = (int)splits;
     // an un-seeded search re-learns its running minimum in every split: keep the first iteration coarser
-    e->q_splits_first = (int)(splits > 16 ? 16 : splits);
+    const size_t first_cap = f32 ? 8 : 16;
+    e->q_splits_first = (int)(splits > first_cap ? first_cap : splits);
     int cb = env_int("ICP_AMD_CB", 32);
     if (cb != 8 && cb != 16 && cb != 32) cb = 32;
+    if (f32 && cb == 8) cb = 16;
     e->cb = cb;
-    // AUTO = the fused pre-filter: identical indices (every candidate is re-evaluated un-fused), 7.1 instead
-    // of 9.1 fp64 VALU instructions per pair
-    int variant = e->opt.search == ICP_AMD_SEARCH_EXACT ? kExact : kFma;
-    const char *sv = getenv("ICP_AMD_SEARCH");
-    if (sv && !strcmp(sv, "fma")) variant = kFma;
-    if (sv && !strcmp(sv, "exact")) variant = kExact;
-    e->variant = variant;
 }
 
 extern "C" int icp_amd_set_source(icp_amd_engine *e, const double *P, size_t n)
@@ -294,7 +316,7 @@ extern "C" int icp_amd_set_source(icp_amd_engine *e, const double *P, size_t n)
     if (n != expect)
         return fail(ICP_AMD_EINVAL, "rank %d of %d must own %zu source rows (got %zu)", e->opt.rank, world, expect, n);
     HIPCHK(hipSetDevice(e->opt.device));
-    const size_t n_pad = round_up(n ? n : 1, kChunk);
+    const size_t n_pad = round_up(n ? n : 1, kPadRows);
     if (n_pad != e->n_pad) {
         free_dev(e->p_store); free_dev(e->idx);
         e->p_store = nullptr; e->idx = nullptr; e->n_pad = 0;
@@ -403,8 +425,12 @@ extern "C" int icp_amd_step_search(icp_amd_engine *e)
         }
         const bool seed = e->have_prev && env_int("ICP_AMD_SEED", 1) != 0;
         const int splits = seed ? e->q_splits : e->q_splits_first;
-        HIPCHK(search(e->stream, e->variant, e->ppl, e->cb, e->P, e->n_pad, e->pc, e->Qz, e->m, e->m_pad, splits,
-                      seed ? e->idx : nullptr, e->keys, e->idxs));
+        if (e->variant == kF32)
+            HIPCHK(search_f32(e->stream, e->ppl, e->cb, e->P, e->n_pad, e->pc, e->Qz, e->qrec, e->qmax, e->m, e->m_pad, splits,
+                              seed ? e->idx : nullptr, e->keys, e->idxs));
+        else
+            HIPCHK(search(e->stream, e->variant, e->ppl, e->cb, e->P, e->n_pad, e->pc, e->Qz, e->m, e->m_pad, splits,
+                          seed ? e->idx : nullptr, e->keys, e->idxs));
         if (e->opt.kernel_timing) HIPCHK(hipEventRecord(b, e->stream));
         HIPCHK(merge_cov(e->stream, e->P, e->n, e->n_pad, e->pc, e->Qz, e->m, splits, e->keys, e->idxs, e->idx, cov_slot));
         e->have_prev = true;
@@ -724,18 +750,21 @@ extern "C" int icp_amd_correspondences(const double *P, size_t n, const double P
     if (n == 0 || m == 0 || n > kMaxRows || m > kMaxRows) return fail(ICP_AMD_EINVAL, "icp_amd_correspondences: bad sizes");
     RCCHK(require_device(env_int("ICP_AMD_DEVICE", 0)));
     hipStream_t s = nullptr;
-    const size_t n_pad = round_up(n, kChunk), m_pad = round_up(m, kTileQ);
-    DevBuf pst, pstage, qst, qstage, pc, keys, idxs, out, part;
+    const size_t n_pad = round_up(n, kPadRows), m_pad = round_up(m, kPadRows);
+    DevBuf pst, pstage, qst, qstage, pc, keys, idxs, out, part, qrec, qmaxb;
     Soa3 dP, dQ;
     RCCHK(upload_soa(s, P, n, n_pad, 0.0, pst, pstage, dP));
     RCCHK(upload_soa(s, Qz, m, m_pad, std::numeric_limits<double>::infinity(), qst, qstage, dQ));
     HIPCHK(pc.alloc(3 * sizeof(double)));
     HIPCHK(hipMemcpyAsync(pc.p, Pc, 3 * sizeof(double), hipMemcpyHostToDevice, s));
-    const size_t tiles = m_pad / kTileQ;
+    const bool f32 = search_variant == ICP_AMD_SEARCH_F32;
+    const size_t tiles = m_pad / (f32 ? 2048 : kTileQ);
     if (q_splits < 1) q_splits = 1;
     if ((size_t)q_splits > tiles) q_splits = (int)tiles;
     int ppl = env_int("ICP_AMD_PPL", 4);
-    if (ppl != 1 && ppl != 2 && ppl != 4) ppl = 4;
+    if (ppl != 1 && ppl != 2 && ppl != 4 && ppl != 8) ppl = 4;
+    if (f32 && ppl == 1) ppl = 2;
+    if (!f32 && ppl == 8) ppl = 4;
     HIPCHK(keys.alloc((size_t)q_splits * n_pad * sizeof(double)));
     HIPCHK(idxs.alloc((size_t)q_splits * n_pad * sizeof(uint32_t)));
     HIPCHK(out.alloc(n_pad * sizeof(uint32_t)));
@@ -743,8 +772,29 @@ extern "C" int icp_amd_correspondences(const double *P, size_t n, const double P
     const int variant = search_variant == ICP_AMD_SEARCH_FMA ? kFma : kExact;
     int cb = env_int("ICP_AMD_CB", 32);
     if (cb != 8 && cb != 16 && cb != 32) cb = 32;
-    HIPCHK(search(s, variant, ppl, cb, dP, n_pad, pc.as<double>(), dQ, m, m_pad, q_splits, nullptr, keys.as<double>(),
-                  idxs.as<uint32_t>()));
+    if (f32) {
+        if (cb == 8) cb = 16;
+        HIPCHK(qrec.alloc(16 * m_pad));
+        HIPCHK(qmaxb.alloc(sizeof(unsigned long long)));
+        HIPCHK(build_qrec(s, dQ, m, m_pad, qrec.p, qmaxb.as<unsigned long long>()));
+        unsigned long long bits = 0;
+        HIPCHK(hipMemcpyAsync(&bits, qmaxb.p, sizeof bits, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        double qmax2;
+        memcpy(&qmax2, &bits, sizeof qmax2);
+        if ((qmax2 == qmax2) && qmax2 > 1e-30 && qmax2 < 1e30) {
+            HIPCHK(search_f32(s, ppl, cb, dP, n_pad, pc.as<double>(), dQ, qrec.p, sqrt(qmax2), m, m_pad, q_splits, nullptr,
+                              keys.as<double>(), idxs.as<uint32_t>()));
+        } else {   // range outside the fp32 bound's domain: same degradation as the engine
+            if (ppl == 8) ppl = 4;
+            const size_t t64 = m_pad / kTileQ;
+            HIPCHK(search(s, kFma, ppl, cb, dP, n_pad, pc.as<double>(), dQ, m, m_pad, q_splits > (int)t64 ? (int)t64 : q_splits,
+                          nullptr, keys.as<double>(), idxs.as<uint32_t>()));
+        }
+    } else {
+        HIPCHK(search(s, variant, ppl, cb, dP, n_pad, pc.as<double>(), dQ, m, m_pad, q_splits, nullptr, keys.as<double>(),
+                      idxs.as<uint32_t>()));
+    }
     HIPCHK(merge_cov(s, dP, n, n_pad, pc.as<double>(), dQ, m, q_splits, keys.as<double>(), idxs.as<uint32_t>(),
                      out.as<uint32_t>(), part.as<double>()));
     HIPCHK(hipMemcpyAsync(idx, out.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost, s));

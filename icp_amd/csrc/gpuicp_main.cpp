@@ -1,5 +1,7 @@
 // GPUICP -- command-line drop-in for the reference's GPU executable (reference src/gpu/main.cu:58-81):
 //   ./GPUICP file1 file2 nbiters method={-loop|-batch|-shared|-shared-loop}
+//   ./GPUICP file1 file2 nbiters -batch count      (additive: file1/file2 hold `count` concatenated clouds of equal
+//                                                   size, registered independently -- BASELINE config 5)
 // Same arguments, same stdout line, same output file; built on the C ABI of libicp_amd.so only.
 // Argument / shape errors throw an uncaught std::runtime_error like the reference's runtime_assert
 // (include/error.hpp:6-15); device errors print and exit(EXIT_FAILURE) like cudaCheckError
@@ -30,7 +32,8 @@ static std::vector<double> load(const char *path, size_t &rows, size_t &cols)
 
 int main(int argc, char **argv)
 {
-    runtime_assert(argc == 5, "Usage: ./GPUICP file1 file2 nbiters method={-loop|-batch|-shared|-shared-loop}");
+    runtime_assert(argc == 5 || (argc == 6 && std::string(argv[4]) == "-batch"),
+                   "Usage: ./GPUICP file1 file2 nbiters method={-loop|-batch|-shared|-shared-loop}");
     size_t Pl, Pc, Ql, Qc;
     std::vector<double> P = load(argv[1], Pl, Pc);
     std::vector<double> Q = load(argv[2], Ql, Qc);
@@ -45,7 +48,14 @@ int main(int argc, char **argv)
     runtime_assert(Pc == 3 && Qc == 3, "element_wise_reduce requires arrays to be broadcastable");
     runtime_assert(Pl > 0 && Ql > 0, "empty point cloud");
     std::vector<double> P_res(Pl * 3);
-    const int rc = icp_amd_run(P.data(), Pl, Q.data(), Ql, nbiters, m, P_res.data(), nullptr);
+    int rc;
+    if (argc == 6) {
+        const size_t count = (size_t)std::stoul(argv[5]);
+        runtime_assert(count > 0 && Pl % count == 0 && Ql % count == 0, "batch count must divide the row counts of both files");
+        rc = icp_amd_run_batch(P.data(), Q.data(), count, Pl / count, Ql / count, nbiters, P_res.data(), nullptr, nullptr, nullptr, nullptr);
+    } else {
+        rc = icp_amd_run(P.data(), Pl, Q.data(), Ql, nbiters, m, P_res.data(), nullptr);
+    }
     if (rc == ICP_AMD_EINVAL) throw std::runtime_error(icp_amd_last_error());
     if (rc != ICP_AMD_OK) {
         printf("HIP failure: %s\n", icp_amd_last_error());

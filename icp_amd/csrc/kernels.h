@@ -13,7 +13,8 @@ constexpr int kTileQ   = 1024;   // target points per LDS tile; Q arrays are pad
 constexpr int kCovW    = 12;     // doubles per cov partial: 9 cov sums, sum d^2, 2 spare
 constexpr int kCenW    = 3;      // doubles per centroid partial
 
-enum SearchVariant { kExact = 1, kFma = 2 };
+enum SearchVariant { kExact = 1, kFma = 2, kF32 = 3 };
+constexpr size_t kPadRows = 2048;  // clouds are padded to this many rows (covers every kernel's tile)
 
 struct Soa3 {            // device SoA view of a cloud
     double *x, *y, *z;
@@ -36,6 +37,14 @@ hipError_t soa_to_aos(hipStream_t s, Soa3 in, size_t n, double *aos);
 hipError_t search(hipStream_t s, int variant, int ppl, int cb, Soa3 P, size_t n_pad, const double *pc,
                   Soa3 Qz, size_t m, size_t m_pad, int q_splits, const uint32_t *idx_prev, double *out_key,
                   uint32_t *out_idx);
+
+// fp32 pre-filter variant.  qrec: m_pad 16-byte records {-2qx,-2qy,-2qz,|q|^2} built by build_qrec, which also
+// leaves the bit pattern of max |q|^2 in *qmax2_bits; qmax = sqrt of that.  n_pad and m_pad multiples of 2048.
+// ppl in {2,4,8}, cb in {16,32}.
+hipError_t build_qrec(hipStream_t s, Soa3 Qz, size_t m, size_t m_pad, void *qrec, unsigned long long *qmax2_bits);
+hipError_t search_f32(hipStream_t s, int ppl, int cb, Soa3 P, size_t n_pad, const double *pc, Soa3 Qz, const void *qrec,
+                      double qmax, size_t m, size_t m_pad, int q_splits, const uint32_t *idx_prev, double *out_key,
+                      uint32_t *out_idx);
 
 // Merge the splits (lowest index among equal keys), write idx[n], and reduce q (x) p per 1024-row chunk
 // into partial[chunk][12].

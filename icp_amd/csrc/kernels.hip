@@ -310,6 +310,150 @@ __global__ __launch_bounds__(kWG) void search_kernel(const double *__restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------------
+// correspondence search with an fp32 pre-filter (MODE f32)
+// ------------------------------------------------------------------------------------------------
+// Same structure and same exact slow path as search_kernel, but the fast path works on
+//     s_j = |q_j|^2 - 2 p.q_j   ( = d^2(p, q_j) - |p|^2, so argmin_j s_j = argmin_j d^2 )
+// in fp32: three v_fma_f32 per pair on a 16-byte target record {-2qx, -2qy, -2qz, |q|^2} and one v_min3_f32 per two
+// pairs -- 3.5 two-cycle instructions per pair instead of 7.1 four-cycle ones.  It is only a filter: with
+// eps = 2^-24, |s_j(fp32) - s_j(real)| <= eps (10.1 |p| |q|max + 4.1 |q|max^2) =: E (five roundings on the products,
+// four on |q|^2), hence every target whose exact fp64 d^2 is below the running exact minimum bd satisfies
+//     s_j(fp32) < bd (1+2^-50) - |p|^2 (1-2^-50) + E,
+// which is the event threshold (rounded up to fp32).  Blocks that trip it are re-evaluated in the oracle's own
+// un-fused fp64 sequence, exactly as in the fp64 modes, so the indices are bit-identical; a cloud for which E is
+// large compared with the nearest-neighbour distances only takes the slow path more often.
+constexpr int kTileQF = 2048;
+
+struct __attribute__((aligned(16))) QRec { float x, y, z, w; };
+
+__device__ __forceinline__ float vmin3f(float a, float b, float c)
+{
+    float r;
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
+__device__ __forceinline__ float f32_above(double x)
+{
+    const float f = (float)x;
+    return __builtin_fmaf(__builtin_fabsf(f), 0x1p-22f, f) + 1e-37f;   // at least one fp32 ulp above x
+}
+
+__global__ __launch_bounds__(kWG) void build_qrec_kernel(const double *__restrict__ qx, const double *__restrict__ qy,
+                                                         const double *__restrict__ qz, size_t m, size_t m_pad,
+                                                         QRec *__restrict__ rec, unsigned long long *__restrict__ qmax2_bits)
+{
+    const size_t i = (size_t)blockIdx.x * kWG + threadIdx.x;
+    double n2 = 0.0;
+    if (i < m_pad) {
+        QRec r{0.0f, 0.0f, 0.0f, INFINITY};   // pad: s = +inf, never an event
+        if (i < m) {
+            const double x = qx[i], y = qy[i], z = qz[i];
+            n2 = x * x + y * y + z * z;
+            r = QRec{(float)(-2.0 * x), (float)(-2.0 * y), (float)(-2.0 * z), (float)n2};
+        }
+        rec[i] = r;
+    }
+    // max |q|^2 over the cloud (positive doubles order like their bit patterns; NaN/inf end up above every finite value)
+    unsigned long long b = (unsigned long long)__double_as_longlong(n2);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        const unsigned long long other = __shfl_xor(b, o, 64);
+        b = other > b ? other : b;
+    }
+    if ((threadIdx.x & 63) == 0) atomicMax(qmax2_bits, b);
+}
+
+template <int PPL, int CB>
+__global__ __launch_bounds__(kWG) void search_f32_kernel(const double *__restrict__ px, const double *__restrict__ py,
+                                                         const double *__restrict__ pz, const double *__restrict__ pc,
+                                                         const double *__restrict__ qx, const double *__restrict__ qy,
+                                                         const double *__restrict__ qz, const QRec *__restrict__ qrec, double qmax,
+                                                         unsigned n_pad, unsigned m, unsigned m_pad, unsigned q_per_split,
+                                                         const uint32_t *__restrict__ idx_prev, double *__restrict__ out_key,
+                                                         uint32_t *__restrict__ out_idx)
+{
+    __shared__ QRec st[kTileQF];
+    const unsigned tid = threadIdx.x;
+    const unsigned base = blockIdx.x * (kWG * PPL) + tid;
+    const double c0 = pc[0], c1 = pc[1], c2 = pc[2];
+
+    float fx[PPL], fy[PPL], fz[PPL], ms[PPL], thr[PPL];
+    double off[PPL];   // E - |p|^2 (1 - 2^-50): threshold = bd (1+2^-50) + off
+    double bd[PPL], bk[PPL];
+    uint32_t bj[PPL];
+#pragma unroll
+    for (int s = 0; s < PPL; ++s) {
+        const double ax = px[base + s * kWG] - c0, ay = py[base + s * kWG] - c1, az = pz[base + s * kWG] - c2;
+        fx[s] = (float)ax;
+        fy[s] = (float)ay;
+        fz[s] = (float)az;
+        const double pn = (ax * ax + ay * ay) + az * az;
+        const double E = 0x1p-24 * (11.0 * sqrt(pn) * qmax + 5.0 * qmax * qmax) + 1e-35;
+        // outside the range where the fp32 bound is meaningful the lane simply always takes the exact path
+        off[s] = (pn < 1e30) ? (E - pn) + pn * 0x1p-50 : INFINITY;
+        bd[s] = INFINITY;
+        bk[s] = INFINITY;
+        bj[s] = 0xFFFFFFFFu;
+        if (idx_prev) {
+            const uint32_t js = idx_prev[base + s * kWG];
+            if (js < m) {
+                const double d = d2_exact(ax, ay, az, qx[js], qy[js], qz[js]);
+                if (d < INFINITY) {
+                    bk[s] = key_of(d);
+                    bj[s] = js;
+                    bd[s] = __builtin_fma(d, 1.0 + 0x1p-48, 1e-300);
+                }
+            }
+        }
+        thr[s] = f32_above(__builtin_fma(bd[s], 1.0 + 0x1p-50, off[s]));
+        ms[s] = thr[s];
+    }
+
+    const unsigned q0 = blockIdx.y * q_per_split;
+    const unsigned q1 = (q0 + q_per_split < m_pad) ? (q0 + q_per_split) : m_pad;
+    for (unsigned t0 = q0; t0 < q1; t0 += kTileQF) {
+        __syncthreads();
+        for (int k = tid; k < kTileQF; k += kWG) st[k] = qrec[t0 + k];
+        __syncthreads();
+        for (int j0 = 0; j0 < kTileQF; j0 += CB) {
+#pragma unroll
+            for (int u = 0; u < CB; u += 2) {
+                const QRec a = st[j0 + u], b = st[j0 + u + 1];
+#pragma unroll
+                for (int s = 0; s < PPL; ++s) {
+                    const float sa = __builtin_fmaf(fz[s], a.z, __builtin_fmaf(fy[s], a.y, __builtin_fmaf(fx[s], a.x, a.w)));
+                    const float sb = __builtin_fmaf(fz[s], b.z, __builtin_fmaf(fy[s], b.y, __builtin_fmaf(fx[s], b.x, b.w)));
+                    ms[s] = vmin3f(ms[s], sa, sb);
+                }
+            }
+            bool ev = false;
+#pragma unroll
+            for (int s = 0; s < PPL; ++s) ev |= (ms[s] < thr[s]);
+            if (ev) {
+#pragma unroll
+                for (int s = 0; s < PPL; ++s) {
+                    if (ms[s] < thr[s]) {
+                        // exact re-evaluation of the block in fp64 from the source arrays (rare: reloaded, not kept in registers)
+                        const double ax = px[base + s * kWG] - c0, ay = py[base + s * kWG] - c1, az = pz[base + s * kWG] - c2;
+                        const unsigned jg = t0 + (unsigned)j0;
+                        rescan_block<CB>(ax, ay, az, qx + jg, qy + jg, qz + jg, 0, jg, bd[s], bk[s], bj[s]);
+                        thr[s] = f32_above(__builtin_fma(bd[s], 1.0 + 0x1p-50, off[s]));
+                        ms[s] = thr[s];
+                    }
+                }
+            }
+        }
+    }
+    const size_t o = (size_t)blockIdx.y * n_pad + base;
+#pragma unroll
+    for (int s = 0; s < PPL; ++s) {
+        out_key[o + s * kWG] = bk[s];
+        out_idx[o + s * kWG] = bj[s];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // merge of the target splits + cross-covariance partials
 // ------------------------------------------------------------------------------------------------
 // cov[a][b] = sum_i Qz[idx[i]][a] * Pz[i][b]  (reference src/cpu/icp.cpp:108-131: q^T . p per point, each
@@ -830,6 +974,40 @@ hipError_t search(hipStream_t s, int variant, int ppl, int cb, Soa3 P, size_t n_
     ICPK_CASE(1, 8) ICPK_CASE(1, 16) ICPK_CASE(1, 32)
     ICPK_CASE(2, 8) ICPK_CASE(2, 16) ICPK_CASE(2, 32)
     ICPK_CASE(4, 8) ICPK_CASE(4, 16) ICPK_CASE(4, 32)
+#undef ICPK_CASE
+    return hipErrorInvalidValue;
+}
+
+hipError_t build_qrec(hipStream_t s, Soa3 Qz, size_t m, size_t m_pad, void *qrec, unsigned long long *qmax2_bits)
+{
+    if (m_pad == 0) return hipErrorInvalidValue;
+    hipError_t e = hipMemsetAsync(qmax2_bits, 0, sizeof(unsigned long long), s);
+    if (e != hipSuccess) return e;
+    build_qrec_kernel<<<blocks_for(m_pad, kWG), kWG, 0, s>>>(Qz.x, Qz.y, Qz.z, m, m_pad, (QRec *)qrec, qmax2_bits);
+    return hipGetLastError();
+}
+
+template <int PPL, int CB>
+static hipError_t search_f32_launch(hipStream_t s, Soa3 P, size_t n_pad, const double *pc, Soa3 Qz, const void *qrec, double qmax,
+                                    size_t m, size_t m_pad, int q_splits, const uint32_t *idx_prev, double *out_key, uint32_t *out_idx)
+{
+    const size_t tiles = m_pad / kTileQF;
+    const unsigned q_per_split = (unsigned)(((tiles + q_splits - 1) / q_splits) * kTileQF);
+    dim3 grid((unsigned)(n_pad / (kWG * PPL)), (unsigned)q_splits);
+    search_f32_kernel<PPL, CB><<<grid, kWG, 0, s>>>(P.x, P.y, P.z, pc, Qz.x, Qz.y, Qz.z, (const QRec *)qrec, qmax, (unsigned)n_pad,
+                                                    (unsigned)m, (unsigned)m_pad, q_per_split, idx_prev, out_key, out_idx);
+    return hipGetLastError();
+}
+
+hipError_t search_f32(hipStream_t s, int ppl, int cb, Soa3 P, size_t n_pad, const double *pc, Soa3 Qz, const void *qrec, double qmax,
+                      size_t m, size_t m_pad, int q_splits, const uint32_t *idx_prev, double *out_key, uint32_t *out_idx)
+{
+    if (n_pad == 0 || m_pad == 0 || n_pad % (kWG * 8) || m_pad % kTileQF || q_splits < 1 || m > m_pad || !(qmax >= 0.0))
+        return hipErrorInvalidValue;
+#define ICPK_CASE(PPL_, CB_) \
+    if (ppl == PPL_ && cb == CB_) \
+        return search_f32_launch<PPL_, CB_>(s, P, n_pad, pc, Qz, qrec, qmax, m, m_pad, q_splits, idx_prev, out_key, out_idx);
+    ICPK_CASE(2, 32) ICPK_CASE(4, 16) ICPK_CASE(4, 32) ICPK_CASE(8, 16) ICPK_CASE(8, 32)
 #undef ICPK_CASE
     return hipErrorInvalidValue;
 }

@@ -44,9 +44,10 @@ extern "C" {
 #define ICP_AMD_METHOD_BATCH       3
 
 /* Correspondence-search kernel variants (engine option `search`); every variant returns identical indices. */
-#define ICP_AMD_SEARCH_AUTO   0
+#define ICP_AMD_SEARCH_AUTO   0   /* = F32 when the clouds' range allows it, else FMA                        */
 #define ICP_AMD_SEARCH_EXACT  1   /* 8 un-fused fp64 ops per pair, the oracle's own sequence                */
 #define ICP_AMD_SEARCH_FMA    2   /* fused fp64 pre-filter + exact re-evaluation of every candidate         */
+#define ICP_AMD_SEARCH_F32    3   /* fp32 pre-filter with a rigorous error bound + the same exact re-evaluation */
 
 typedef struct icp_amd_engine icp_amd_engine;
 

@@ -59,3 +59,24 @@ def test_batch_variants_and_limits():
     for shape in ((1, 2049, 100), (1, 100, 4097), (0, 10, 10), (1, 0, 10)):
         with pytest.raises(icp_amd.IcpAmdError):
             icp_amd.Batch(*shape)
+
+
+def test_cli_batch_argument(tmp_path):
+    import os
+    import subprocess
+    from conftest import ROOT
+    P, Q = synth.make_batch(3, 200)
+    for name, A in (("P.txt", P), ("Q.txt", Q)):
+        with open(tmp_path / name, "w") as f:
+            for r in A.reshape(-1, 3):
+                f.write("%.17g,%.17g,%.17g\n" % tuple(r))
+    exe = os.path.join(ROOT, "bin", "GPUICP")
+    r = subprocess.run([exe, "P.txt", "Q.txt", "4", "-batch", "3"], cwd=tmp_path, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    lines = open(tmp_path / "point_cloud_result").read().split("\n")
+    assert lines[0] == " dim0: 600 dim1: 3 array: "
+    got = np.array([[float(v) for v in ln.split()] for ln in lines[1:601]])
+    want = icp_amd.icp_gpu_batch(P, Q, 4)["P_out"].reshape(-1, 3)
+    assert np.abs(got - want).max() < 1e-4
+    r = subprocess.run([exe, "P.txt", "Q.txt", "4", "-batch", "7"], cwd=tmp_path, capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "batch count must divide" in r.stderr

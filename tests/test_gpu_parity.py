@@ -42,7 +42,7 @@ def test_stagewise_against_reference(name):
     for slot, it in enumerate(g["P_in_iters"]):
         P_in, Pc = g["P_in"][slot], g["Pc"][it]
         assert relerr(icp_amd.centroid(P_in), Pc) < 1e-13
-        for search, splits in (("exact", 1), ("fma", 1), ("exact", 3), ("fma", 5)):
+        for search, splits in (("exact", 1), ("fma", 1), ("f32", 1), ("exact", 3), ("fma", 5), ("f32", 2)):
             idx = icp_amd.correspondences(P_in, Pc, Qz, search=search, q_splits=splits)
             assert np.array_equal(idx, g["idx"][it]), (name, it, search, splits, int((idx != g["idx"][it]).sum()))
         cov = icp_amd.cross_cov(P_in, Pc, Qz, g["idx"][it])
@@ -69,6 +69,27 @@ def test_whole_loop_against_reference(name):
     assert relerr(P_out, g["P_out"]) < TOL
 
 
+def test_f32_prefilter_whole_loop_and_scale_robustness(monkeypatch):
+    """The fp32 pre-filter is only a filter: whole-loop results equal the default path bit for bit, also for clouds
+    whose scale / offset make the fp32 error bound loose (many slow-path visits) or unusable (falls back)."""
+    monkeypatch.setenv("ICP_AMD_SEARCH", "f32")
+    for name in ("cow_tr1", "syn3k_4k", "lattice", "c1_30pts"):
+        g = golden(name)
+        P_out, tr = icp_amd.icp_gpu_optimized(g["P"], g["Q"], int(g["iters"]), trace=True)
+        assert np.array_equal(tr["idx"], g["idx"]), name
+        assert relerr(P_out, g["P_out"]) < TOL
+    monkeypatch.delenv("ICP_AMD_SEARCH")
+    P, Q = synth.make_pair(5000, 6000, seed=77)
+    for scale, shift in ((1.0, 0.0), (1e-6, 0.0), (1e6, 0.0), (1.0, 1e4), (1e-3, 50.0), (1e20, 0.0), (1e-20, 0.0)):
+        Ps, Qs = P * scale + shift, Q * scale + shift
+        a, ta = icp_amd.icp_gpu_optimized(Ps, Qs, 2, trace=True)
+        monkeypatch.setenv("ICP_AMD_SEARCH", "f32")
+        b, tb = icp_amd.icp_gpu_optimized(Ps, Qs, 2, trace=True)
+        monkeypatch.delenv("ICP_AMD_SEARCH")
+        assert np.array_equal(ta["idx"], tb["idx"]), (scale, shift)
+        assert np.array_equal(a, b), (scale, shift)
+
+
 @pytest.mark.parametrize("method", ["-loop", "-shared", "-shared-loop", "-batch"])
 def test_all_method_flags_give_the_same_result(method):
     g = golden("syn256")
@@ -81,7 +102,7 @@ def test_all_method_flags_give_the_same_result(method):
 
 def test_adversarial_ties():
     g = golden("ties_corr")
-    for search in ("exact", "fma"):
+    for search in ("exact", "fma", "f32"):
         for splits in (1, 2):
             idx = icp_amd.correspondences(g["Pz"], np.zeros(3), g["Qz"], search=search, q_splits=splits)
             assert np.array_equal(idx, g["idx"]), (search, splits)
@@ -94,8 +115,8 @@ def test_edge_shapes():
         Pc = orc.mean0(P)
         Qz = Q - orc.mean0(Q)
         want = orc.correspondences(P - Pc, Qz)
-        for search in ("exact", "fma"):
-            assert np.array_equal(icp_amd.correspondences(P, Pc, Qz, search=search, q_splits=2), want), (n, m)
+        for search in ("exact", "fma", "f32"):
+            assert np.array_equal(icp_amd.correspondences(P, Pc, Qz, search=search, q_splits=2), want), (n, m, search)
         out = orc.icp(P, Q, 2, trace=True)
         P_out, tr = icp_amd.icp_gpu_optimized(P, Q, 2, trace=True)
         assert np.array_equal(tr["idx"], out["idx"])
@@ -126,7 +147,8 @@ def test_full_size_properties_c3():
     of the launch geometry (target splits, points per lane, kernel variant)."""
     P, Q = synth.make_pair(100000, 100000)
     results = []
-    for kw in (dict(search="exact"), dict(search="fma"), dict(search="exact", q_splits=7), dict(search="exact")):
+    for kw in (dict(search="exact"), dict(search="fma"), dict(search="f32"), dict(search="exact", q_splits=7),
+               dict(search="f32", q_splits=3), dict(search="exact")):
         e = icp_amd.Engine(**kw)
         e.set_target(Q)
         e.set_source(P)

@@ -32,6 +32,8 @@ for var, ppl, cb, sp, seed in itertools.product(variants, ppls, cbs, splits, see
     k_ms = e.kernel_ms()[0]
     g = e.search_geometry()
     e.close()
+    if g["variant"] != var:
+        print("(requested %s ppl=%d, engine chose %s)" % (var, ppl, g["variant"]))
     frac = 8.0 * n * m / (k_ms * 1e-3) / 39.3e12
     print("%-5s ppl=%d cb=%2d splits=%2d seed=%d wgs=%5d | iter %.3f ms  search %.3f ms (first, unseeded %.3f)  frac_of_39.3TF %.3f  evals/s %.3e"
           % (var, ppl, cb, g["q_splits"], seed, g["workgroups"], ms, k_ms, first_ms, frac, n * float(m) / (ms * 1e-3)), flush=True)
