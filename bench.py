@@ -22,10 +22,51 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP64_VALU_NOFMA = 39.3e12   # 256 CU x 4 SIMD x 16 fp64 lanes/clk x 2.4 GHz, one flop per op
+PEAK_FP32_VALU = 157.3e12        # MI355X fp32 vector peak (MI355X_MICROARCH.md; packed FMA counted as 2 flops per lane)
 FLOPS_PER_PAIR = 8               # 3 sub, 3 mul, 2 add: the oracle's un-fused distance
 
 
-def cpu_baseline(P, Q, seconds_target=15.0):
+def roofline(variant, n_local, M, avg_ms, launches):
+    """Roofline object of the search kernel.  `achieved` is ALGORITHMIC: 8 flops per (p,q) pair x the
+    pairs of one launch / the kernel's hipEvent-timed average launch duration, whatever instruction mix the variant's
+    fast path really issues; `peak` is the VALU peak of the arithmetic type that fast path runs in."""
+    ach = FLOPS_PER_PAIR * float(n_local) * float(M) / (avg_ms * 1e-3) if avg_ms > 0 else 0.0
+    f32 = variant == "f32"
+    peak = PEAK_FP32_VALU if f32 else PEAK_FP64_VALU_NOFMA
+    mix = {"f32": "fast path = fp32 pre-filter, 3 v_fma_f32 (or 1.5 v_pk_fma_f32) + 0.5 v_min3_f32 per pair; every candidate "
+                  "re-evaluated in un-fused fp64 (indices bit-identical to the fp64 variants)",
+           "fma": "fast path = 7.08 fp64 VALU instructions per pair (3 add, 1 mul, 2 fma, 1 min); candidates re-evaluated un-fused",
+           "exact": "fast path = 9.08 fp64 VALU instructions per pair (the oracle's 8 un-fused ops + 1 min)"}.get(variant, variant)
+    return {"bound": "valu_fp32" if f32 else "valu_fp64", "kernel": "search_f32_kernel" if f32 else "search_kernel",
+            "achieved": ach / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s", "frac": ach / peak,
+            "flops_per_pair": FLOPS_PER_PAIR, "pairs_per_launch": float(n_local) * float(M), "avg_launch_ms": avg_ms,
+            "launches": launches, "traffic": None, "variant": variant, "instruction_mix": mix,
+            "note": ("fp32 vector peak 157.3 TFLOP/s" if f32 else
+                     "un-fused fp64 VALU peak 39.3 TFLOP/s = one flop per op (FMA-counted datasheet peak: 78.6)")}
+
+
+def fp64_variants(P, Q, device, steps=3):
+    """The same workload through the two fp64-only search variants (N = 1 only), for the fp64-VALU roofline the
+    north star names.  Results are bit-identical to the default path (asserted by tests/test_gpu_parity.py)."""
+    import icp_amd
+    out = {}
+    for var in ("fma", "exact"):
+        e = icp_amd.Engine(device=device, search=var, kernel_timing=True)
+        e.set_target(Q)
+        e.set_source(P)
+        e.iterate(2)                      # first iteration is un-seeded
+        e.sync()
+        e.kernel_ms()
+        ms = e.iterate_timed(steps) / steps
+        k_ms, _, launches = e.kernel_ms()
+        geo = e.search_geometry()
+        e.close()
+        out[var] = {"ms_per_step": ms, "value": float(len(P)) * len(Q) / (ms * 1e-3), "unit": "distance evals/s",
+                    "search": geo, "roofline": roofline(var, len(P), len(Q), k_ms, launches)}
+    return out
+
+
+def cpu_baseline(P, Q, seconds_target=30.0):
     """The CPU oracle (oracle/icp_oracle.c, a port of the reference CPU path) timed on this host's cores on a
     bounded sample of the same workload: the correspondence search of the first `rows` source points against
     the whole target (the search is >99% of an iteration)."""
@@ -113,6 +154,7 @@ def main():
     ap.add_argument("--m", type=int, default=1000000, help="target points")
     ap.add_argument("--search", default=os.environ.get("ICP_AMD_SEARCH", "auto"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fp64-variants", action="store_true", help="skip the extra fp64-only search variants at N=1")
     ap.add_argument("--workload", default="sharded", choices=["sharded", "batch"],
                     help="sharded: BASELINE configs[3] (default, the headline metric); batch: configs[4], 4096 x (1k x 1k)")
     ap.add_argument("--batch", type=int, default=4096)
@@ -174,8 +216,6 @@ def main():
         pairs = float(N) * float(M)
         evals_per_s = pairs * args.steps / dt
         n_local = runner.n_local
-        # roofline of the dominant kernel (the correspondence search) from its own hipEvent-timed launches
-        ach = FLOPS_PER_PAIR * float(n_local) * float(M) / (search_avg_ms * 1e-3) if search_avg_ms > 0 else 0.0
         out = {
             "metric": "distance_evals_per_sec", "value": evals_per_s, "unit": "distance evals/s",
             "iters_per_sec": args.steps / dt,
@@ -184,19 +224,20 @@ def main():
             "config": {"workload": "BASELINE configs[3]: synthetic %d x %d points, source rows sharded over %d GPU(s), "
                                    "target replicated" % (N, M, world),
                        "n": N, "m": M, "parallelism": "p-shard%d" % world, "search": geo},
-            "roofline": {"bound": "valu_fp64", "kernel": "search_kernel", "achieved": ach / 1e12,
-                         "peak": PEAK_FP64_VALU_NOFMA / 1e12, "unit": "TFLOP/s", "frac": ach / PEAK_FP64_VALU_NOFMA,
-                         "flops_per_pair": FLOPS_PER_PAIR, "pairs_per_launch": float(n_local) * float(M),
-                         "avg_launch_ms": search_avg_ms, "launches": launches, "traffic": None,
-                         "note": "peak counts one flop per fp64 VALU op (the oracle's distance is un-fused); "
-                                 "FMA-counted datasheet peak is 78.6 TFLOP/s"},
+            # dominant kernel (the correspondence search, > 99 % of the step), from its own hipEvent-timed launches
+            "roofline": roofline(geo["variant"], n_local, M, search_avg_ms, launches),
             "rms_last": last["rms"],
         }
+        print_out = out
+    runner.close()
+    if rank == 0:
+        out = print_out
+        if world == 1 and not args.no_fp64_variants:
+            out["fp64_variants"] = fp64_variants(P, Q, local_rank)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(P, Q)
-            out["gpu_over_cpu"] = evals_per_s / out["cpu_baseline"]["value"]
+            out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out), flush=True)
-    runner.close()
     if world > 1:
         td.barrier()
         td.destroy_process_group()

@@ -15,6 +15,7 @@
 #include "kernels.h"
 
 #include <math.h>
+#include <stdlib.h>
 
 namespace icpk {
 
@@ -324,14 +325,13 @@ __global__ __launch_bounds__(kWG) void search_kernel(const double *__restrict__ 
 // large compared with the nearest-neighbour distances only takes the slow path more often.
 constexpr int kTileQF = 2048;
 
-struct __attribute__((aligned(16))) QRec { float x, y, z, w; };
+// Two consecutive targets a, b share one 32-byte record {a.x,b.x, a.y,b.y, a.z,b.z, a.w,b.w} (w = |q|^2), the
+// operand shape of v_pk_fma_f32: one packed FMA advances both targets for one source point.
+struct __attribute__((aligned(16))) QRec { float x, y, z, w; };   // half a pair record (16 bytes)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ float vmin3f(float a, float b, float c)
-{
-    float r;
-    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
+// v_min3_f32 (the compiler fuses the two fminf; an asm statement here would pin the schedule of the packed FMAs)
+__device__ __forceinline__ float vmin3f(float a, float b, float c) { return __builtin_fminf(__builtin_fminf(a, b), c); }
 
 __device__ __forceinline__ float f32_above(double x)
 {
@@ -352,7 +352,11 @@ __global__ __launch_bounds__(kWG) void build_qrec_kernel(const double *__restric
             n2 = x * x + y * y + z * z;
             r = QRec{(float)(-2.0 * x), (float)(-2.0 * y), (float)(-2.0 * z), (float)n2};
         }
-        rec[i] = r;
+        float *o = (float *)rec + (i >> 1) * 8 + (i & 1);   // pair-interleaved layout
+        o[0] = r.x;
+        o[2] = r.y;
+        o[4] = r.z;
+        o[6] = r.w;
     }
     // max |q|^2 over the cloud (positive doubles order like their bit patterns; NaN/inf end up above every finite value)
     unsigned long long b = (unsigned long long)__double_as_longlong(n2);
@@ -364,7 +368,7 @@ __global__ __launch_bounds__(kWG) void build_qrec_kernel(const double *__restric
     if ((threadIdx.x & 63) == 0) atomicMax(qmax2_bits, b);
 }
 
-template <int PPL, int CB>
+template <int PPL, int CB, bool PK>
 __global__ __launch_bounds__(kWG) void search_f32_kernel(const double *__restrict__ px, const double *__restrict__ py,
                                                          const double *__restrict__ pz, const double *__restrict__ pc,
                                                          const double *__restrict__ qx, const double *__restrict__ qy,
@@ -417,15 +421,39 @@ __global__ __launch_bounds__(kWG) void search_f32_kernel(const double *__restric
         for (int k = tid; k < kTileQF; k += kWG) st[k] = qrec[t0 + k];
         __syncthreads();
         for (int j0 = 0; j0 < kTileQF; j0 += CB) {
+            // software-pipelined over pairs of targets: the LDS reads of pair u+1 are in flight while pair u is computed
+            const f32x2 *pr = (const f32x2 *)&st[j0];
+            f32x2 X = pr[0], Y = pr[1], Z = pr[2], W = pr[3];
 #pragma unroll
             for (int u = 0; u < CB; u += 2) {
-                const QRec a = st[j0 + u], b = st[j0 + u + 1];
-#pragma unroll
-                for (int s = 0; s < PPL; ++s) {
-                    const float sa = __builtin_fmaf(fz[s], a.z, __builtin_fmaf(fy[s], a.y, __builtin_fmaf(fx[s], a.x, a.w)));
-                    const float sb = __builtin_fmaf(fz[s], b.z, __builtin_fmaf(fy[s], b.y, __builtin_fmaf(fx[s], b.x, b.w)));
-                    ms[s] = vmin3f(ms[s], sa, sb);
+                f32x2 Xn = X, Yn = Y, Zn = Z, Wn = W;
+                if (u + 2 < CB) {
+                    Xn = pr[(u + 2) * 2 + 0];
+                    Yn = pr[(u + 2) * 2 + 1];
+                    Zn = pr[(u + 2) * 2 + 2];
+                    Wn = pr[(u + 2) * 2 + 3];
                 }
+                if (PK) {
+                    // stage by stage over the PPL independent chains: a dependent v_pk_fma_f32 right behind its producer
+                    // costs a wait state
+                    f32x2 t[PPL];
+#pragma unroll
+                    for (int s = 0; s < PPL; ++s) t[s] = __builtin_elementwise_fma((f32x2){fx[s], fx[s]}, X, W);
+#pragma unroll
+                    for (int s = 0; s < PPL; ++s) t[s] = __builtin_elementwise_fma((f32x2){fy[s], fy[s]}, Y, t[s]);
+#pragma unroll
+                    for (int s = 0; s < PPL; ++s) t[s] = __builtin_elementwise_fma((f32x2){fz[s], fz[s]}, Z, t[s]);
+#pragma unroll
+                    for (int s = 0; s < PPL; ++s) ms[s] = vmin3f(ms[s], t[s].x, t[s].y);
+                } else {
+#pragma unroll
+                    for (int s = 0; s < PPL; ++s) {
+                        const float sa = __builtin_fmaf(fz[s], Z.x, __builtin_fmaf(fy[s], Y.x, __builtin_fmaf(fx[s], X.x, W.x)));
+                        const float sb = __builtin_fmaf(fz[s], Z.y, __builtin_fmaf(fy[s], Y.y, __builtin_fmaf(fx[s], X.y, W.y)));
+                        ms[s] = vmin3f(ms[s], sa, sb);
+                    }
+                }
+                X = Xn; Y = Yn; Z = Zn; W = Wn;
             }
             bool ev = false;
 #pragma unroll
@@ -987,14 +1015,14 @@ hipError_t build_qrec(hipStream_t s, Soa3 Qz, size_t m, size_t m_pad, void *qrec
     return hipGetLastError();
 }
 
-template <int PPL, int CB>
+template <int PPL, int CB, bool PK>
 static hipError_t search_f32_launch(hipStream_t s, Soa3 P, size_t n_pad, const double *pc, Soa3 Qz, const void *qrec, double qmax,
                                     size_t m, size_t m_pad, int q_splits, const uint32_t *idx_prev, double *out_key, uint32_t *out_idx)
 {
     const size_t tiles = m_pad / kTileQF;
     const unsigned q_per_split = (unsigned)(((tiles + q_splits - 1) / q_splits) * kTileQF);
     dim3 grid((unsigned)(n_pad / (kWG * PPL)), (unsigned)q_splits);
-    search_f32_kernel<PPL, CB><<<grid, kWG, 0, s>>>(P.x, P.y, P.z, pc, Qz.x, Qz.y, Qz.z, (const QRec *)qrec, qmax, (unsigned)n_pad,
+    search_f32_kernel<PPL, CB, PK><<<grid, kWG, 0, s>>>(P.x, P.y, P.z, pc, Qz.x, Qz.y, Qz.z, (const QRec *)qrec, qmax, (unsigned)n_pad,
                                                     (unsigned)m, (unsigned)m_pad, q_per_split, idx_prev, out_key, out_idx);
     return hipGetLastError();
 }
@@ -1004,9 +1032,11 @@ hipError_t search_f32(hipStream_t s, int ppl, int cb, Soa3 P, size_t n_pad, cons
 {
     if (n_pad == 0 || m_pad == 0 || n_pad % (kWG * 8) || m_pad % kTileQF || q_splits < 1 || m > m_pad || !(qmax >= 0.0))
         return hipErrorInvalidValue;
+    static const bool pk = !(getenv("ICP_AMD_PK") && atoi(getenv("ICP_AMD_PK")) == 0);
 #define ICPK_CASE(PPL_, CB_) \
     if (ppl == PPL_ && cb == CB_) \
-        return search_f32_launch<PPL_, CB_>(s, P, n_pad, pc, Qz, qrec, qmax, m, m_pad, q_splits, idx_prev, out_key, out_idx);
+        return pk ? search_f32_launch<PPL_, CB_, true>(s, P, n_pad, pc, Qz, qrec, qmax, m, m_pad, q_splits, idx_prev, out_key, out_idx) \
+                  : search_f32_launch<PPL_, CB_, false>(s, P, n_pad, pc, Qz, qrec, qmax, m, m_pad, q_splits, idx_prev, out_key, out_idx);
     ICPK_CASE(2, 32) ICPK_CASE(4, 16) ICPK_CASE(4, 32) ICPK_CASE(8, 16) ICPK_CASE(8, 32)
 #undef ICPK_CASE
     return hipErrorInvalidValue;
