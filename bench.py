@@ -122,7 +122,7 @@ def bench_batch(args, rank, world, local_rank):
     dt = time.perf_counter() - t0
     if world > 1:
         import torch.distributed as td
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda" if td.get_backend() == "nccl" else "cpu")
         td.all_reduce(tmax, op=td.ReduceOp.MAX)
         dt = float(tmax.item())
     if rank == 0:
@@ -150,8 +150,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--n", type=int, default=1000000, help="source points (global)")
-    ap.add_argument("--m", type=int, default=1000000, help="target points")
+    ap.add_argument("--src", dest="n", type=int, default=1000000, help="source points (global)")
+    ap.add_argument("--tgt", dest="m", type=int, default=1000000, help="target points")
     ap.add_argument("--search", default=os.environ.get("ICP_AMD_SEARCH", "auto"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fp64-variants", action="store_true", help="skip the extra fp64-only search variants at N=1")
@@ -176,10 +176,17 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    # rehearsal knobs (tests only): several ranks on one GPU over gloo, e.g. ICP_AMD_BENCH_DEVICE=0 ICP_AMD_BENCH_BACKEND=gloo
+    if os.environ.get("ICP_AMD_BENCH_DEVICE"):
+        local_rank = int(os.environ["ICP_AMD_BENCH_DEVICE"])
+    backend = os.environ.get("ICP_AMD_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     if world > 1:
         import torch.distributed as td
-        td.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            td.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            td.init_process_group(backend)
 
     if args.workload == "batch":
         return bench_batch(args, rank, world, local_rank)
@@ -205,7 +212,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         td.all_reduce(tmax, op=td.ReduceOp.MAX)
         dt = float(tmax.item())
     search_avg_ms, _, launches = runner.engine.kernel_ms()

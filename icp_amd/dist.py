@@ -30,8 +30,11 @@ def exchange_partials(buf, width, rank, world, group=None):
     per = buf.numel() // world
     mine = buf[rank * per:(rank + 1) * per].clone()
     if td.get_backend(group) == "gloo":
-        parts = [buf[r * per:(r + 1) * per] for r in range(world)]
-        td.all_gather(parts, mine, group=group)
+        # gloo (tests, CPU rehearsals) has no device all-gather: stage through the host
+        host = [mine.new_empty(per, device="cpu") for _ in range(world)]
+        td.all_gather(host, mine.cpu(), group=group)
+        for r in range(world):
+            buf[r * per:(r + 1) * per].copy_(host[r])
     else:
         td.all_gather_into_tensor(buf, mine, group=group)
     return buf

@@ -32,11 +32,10 @@ def rotation(angle, axis=(1.0, 2.0, 3.0)):
 
 def make_pair(n, m=None, seed=SEED_Q, angle=0.10, t0=(0.05, -0.03, 0.02), sigma=1e-3):
     """Returns (P[n,3], Q[m,3]) float64, C-contiguous.  P is built from the first n rows of a
-    pseudo-random permutation of Q (n <= m)."""
+    pseudo-random permutation of Q (cycled when n > m)."""
     m = n if m is None else m
-    assert n <= m
     Q = 2.0 * uniform01(seed, 3 * m).reshape(m, 3) - 1.0
-    perm = np.argsort(splitmix64(seed + 1, m), kind="stable")[:n]
+    perm = np.argsort(splitmix64(seed + 1, m), kind="stable")[np.arange(n) % m]
     u = uniform01(seed + 2, 6 * n).reshape(n, 6)
     g = np.sqrt(-2.0 * np.log(1.0 - u[:, :3])) * np.cos(2.0 * np.pi * u[:, 3:])
     P = Q[perm] @ rotation(angle).T + np.asarray(t0) + sigma * g

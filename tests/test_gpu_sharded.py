@@ -104,3 +104,28 @@ def test_torch_stream_and_single_rank_process_group():
     e.close()
     b_out, tr = icp_amd.icp_gpu_optimized(P, Q, 2, trace=True)
     assert np.array_equal(tr["idx"][1], a["idx"]) and np.array_equal(tr["cov"][1], a["cov"])
+
+
+def test_bench_two_ranks_on_one_gpu_over_gloo():
+    """bench.py's multi-rank path end to end (torch.distributed.run, 2 processes, ShardedIcp with caller-owned exchange
+    buffers on its own stream) rehearsed on the one GPU of this box with the gloo backend standing in for RCCL."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, ICP_AMD_BENCH_DEVICE="0", ICP_AMD_BENCH_BACKEND="gloo", OMP_NUM_THREADS="4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29577", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--src", "60000", "--tgt", "50000"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["parallelism"] == "p-shard2"
+    # same workload on one rank: the registration must reach the same rms (bit-identical results whatever the sharding)
+    r1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--src", "60000", "--tgt", "50000",
+                         "--no-cpu-baseline", "--no-fp64-variants"], env=env, capture_output=True, text=True, timeout=280)
+    assert r1.returncode == 0, r1.stderr[-3000:]
+    d1 = json.loads([ln for ln in r1.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d1["rms_last"] == d["rms_last"]
