@@ -200,6 +200,8 @@ static int ensure_stage(icp_amd_engine *e, size_t rows)
     return ICP_AMD_OK;
 }
 
+static int plan_search(icp_amd_engine *e);
+
 static const size_t kMaxRows = 0x7FFFFC00u;  // indices are 32-bit; padded sizes must fit too
 
 extern "C" int icp_amd_set_target(icp_amd_engine *e, const double *Q, size_t m)
@@ -241,6 +243,8 @@ extern "C" int icp_amd_set_target(icp_amd_engine *e, const double *Q, size_t m)
     e->f32_ok = (qmax2 == qmax2) && qmax2 > 1e-30 && qmax2 < 1e30;
     e->qmax = e->f32_ok ? sqrt(qmax2) : 0.0;
     e->have_target = true;
+    e->have_prev = false;                       // correspondences into the previous target are no seed for this one
+    if (e->have_source) RCCHK(plan_search(e));  // the variant and the splits depend on the target
     return ICP_AMD_OK;
 }
 
@@ -302,6 +306,21 @@ static void choose_geometry(icp_amd_engine *e)
     e->cb = cb;
 }
 
+// Launch geometry + the per-split (key, idx) scratch it needs; re-run whenever the source or the target changes.
+static int plan_search(icp_amd_engine *e)
+{
+    choose_geometry(e);
+    const size_t need = (size_t)e->q_splits * e->n_pad;
+    if (need > e->split_cap) {
+        free_dev(e->keys); free_dev(e->idxs);
+        e->keys = nullptr; e->idxs = nullptr; e->split_cap = 0;
+        HIPCHK(hipMalloc(&e->keys, need * sizeof(double)));
+        HIPCHK(hipMalloc(&e->idxs, need * sizeof(uint32_t)));
+        e->split_cap = need;
+    }
+    return ICP_AMD_OK;
+}
+
 extern "C" int icp_amd_set_source(icp_amd_engine *e, const double *P, size_t n)
 {
     if (!e || (!P && n)) return fail(ICP_AMD_EINVAL, "icp_amd_set_source: NULL argument");
@@ -344,15 +363,7 @@ extern "C" int icp_amd_set_source(icp_amd_engine *e, const double *P, size_t n)
         e->own_part = true;
     }
     e->total_chunks = total;
-    choose_geometry(e);
-    const size_t need = (size_t)e->q_splits * n_pad;
-    if (need > e->split_cap) {
-        free_dev(e->keys); free_dev(e->idxs);
-        e->keys = nullptr; e->idxs = nullptr; e->split_cap = 0;
-        HIPCHK(hipMalloc(&e->keys, need * sizeof(double)));
-        HIPCHK(hipMalloc(&e->idxs, need * sizeof(uint32_t)));
-        e->split_cap = need;
-    }
+    RCCHK(plan_search(e));
     // this rank's slots of the partial arrays: unused trailing records stay zero for the whole run
     double *cov_slot = e->cov_part + (size_t)e->opt.rank * cpr * kCovW;
     double *cen_slot = e->cen_part + (size_t)e->opt.rank * cpr * kCenW;

@@ -180,6 +180,49 @@ def test_full_size_properties_c3():
     assert base["rms"] < last["rms"]
 
 
+def test_full_size_properties_c4_1m():
+    """BASELINE config 4 size on one GPU (1M x 1M): sampled rows against the oracle, and all three search variants agree."""
+    P, Q = synth.make_pair(1000000, 1000000)
+    outs = {}
+    for search in ("f32", "fma"):
+        e = icp_amd.Engine(search=search)
+        e.set_target(Q)
+        e.set_source(P)
+        e.iterate(2)
+        outs[search] = (e.get_last(), e.get_source(), e.target_centroid())
+        e.close()
+    a, b = outs["f32"], outs["fma"]
+    assert np.array_equal(a[0]["idx"], b[0]["idx"]) and np.array_equal(a[0]["cov"], b[0]["cov"]) and np.array_equal(a[1], b[1])
+    e = icp_amd.Engine()
+    e.set_target(Q)
+    e.set_source(P)
+    e.iterate(1)
+    last = e.get_last()
+    e.close()
+    rows = np.random.RandomState(3).choice(1000000, 400, replace=False)
+    want = orc.correspondences((P - last["Pc"])[rows], Q - a[2], nthreads=16)
+    assert np.array_equal(last["idx"][rows], want)
+    assert relerr(last["Pc"], orc.mean0(P)) < 1e-13
+    assert relerr(last["cov"], orc.cross_cov(P - last["Pc"], Q - a[2], last["idx"])) < 1e-11
+
+
+def test_target_can_be_replaced_under_an_existing_source():
+    """set_target after set_source re-plans the search (variant, splits) for the new target."""
+    P, Q1 = synth.make_pair(3000, 5000, seed=31)
+    _, Q2 = synth.make_pair(3000, 2500, seed=32)
+    e = icp_amd.Engine()
+    e.set_target(Q1)
+    e.set_source(P)
+    e.iterate(1)
+    e.set_source(P * 1e25)
+    e.set_target(Q2 * 1e25)          # outside the fp32 pre-filter's range: must fall back, not mis-filter
+    e.iterate(2)
+    got = e.get_last()["idx"]
+    e.close()
+    ref = orc.icp(P * 1e25, Q2 * 1e25, 2, trace=True, nthreads=4)
+    assert np.array_equal(got, ref["idx"][-1])
+
+
 def test_cli_matches_reference_output(tmp_path):
     """GPUICP on the 30-point pair: same stdout line shape, same output file format as the reference
     (reference src/gpu/main.cu:79-80); usage and method errors abort like runtime_assert."""
