@@ -18,7 +18,7 @@ $(CSRC)/hostio.o: $(CSRC)/hostio.cpp include/icp_amd.h
 	$(CXX) -O2 -std=c++17 -fPIC -ffp-contract=off -Wall -Wextra -c $< -o $@
 
 $(LIB): $(CSRC)/kernels.o $(CSRC)/engine.o $(CSRC)/hostio.o
-	$(HIPCC) --offload-arch=$(ARCH) -shared -o $@ $^
+	$(HIPCC) --offload-arch=$(ARCH) -shared -o $@ $^ -ldl
 
 bin/GPUICP: $(CSRC)/gpuicp_main.cpp $(LIB) include/icp_amd.h
 	@mkdir -p bin

@@ -12,7 +12,7 @@ import numpy as np
 from . import _lib
 from ._lib import METHODS, SEARCH, IcpAmdError, Options, Trace, check, lib
 
-__all__ = ["icp_gpu_optimized", "icp_gpu", "icp_gpu_batch", "Batch", "Engine", "read_csv", "write_cloud", "euclidian_distance",
+__all__ = ["icp_gpu_optimized", "icp_gpu", "icp_gpu_multi", "icp_gpu_batch", "Batch", "Engine", "read_csv", "write_cloud", "euclidian_distance",
            "correspondences", "cross_cov", "centroid", "solve", "apply", "rows_per_rank", "chunks_per_rank",
            "IcpAmdError", "device_count"]
 
@@ -56,6 +56,23 @@ def icp_gpu_optimized(P, Q, iterations, method="-shared-loop", trace=False):
         tr = Trace(**{k: v.ctypes.data for k, v in d.items()})
     check(lib().icp_amd_run(_p(P), C.c_size_t(n), _p(Q), C.c_size_t(Q.shape[0]), C.c_uint(iterations),
                             C.c_int(METHODS[method]), _p(out), C.byref(tr) if tr is not None else None))
+    return (out, d) if trace else out
+
+
+def icp_gpu_multi(P, Q, iterations, n_gpus, devices=None, trace=False):
+    """icp_amd_run_multi: source rows sharded over n_gpus devices of this node, one process, RCCL all-gathers."""
+    P, Q = _f64(P), _f64(Q)
+    n = P.shape[0]
+    out = np.empty_like(P)
+    tr, d = None, None
+    if trace:
+        d = dict(Pc=np.empty((iterations, 3)), idx=np.empty((iterations, n), dtype=np.int32),
+                 cov=np.empty((iterations, 3, 3)), S=np.empty((iterations, 3)), R=np.empty((iterations, 3, 3)),
+                 t=np.empty((iterations, 3)), rms=np.empty(iterations))
+        tr = Trace(**{k: v.ctypes.data for k, v in d.items()})
+    devs = None if devices is None else (C.c_int * n_gpus)(*devices)
+    check(lib().icp_amd_run_multi(_p(P), C.c_size_t(n), _p(Q), C.c_size_t(Q.shape[0]), C.c_uint(iterations), C.c_int(n_gpus),
+                                  devs, _p(out), C.byref(tr) if tr is not None else None))
     return (out, d) if trace else out
 
 

@@ -6,6 +6,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
@@ -603,6 +604,141 @@ extern "C" int icp_amd_run(const double *P, size_t n, const double *Q, size_t m,
     if (rc == ICP_AMD_OK) rc = icp_amd_get_source(e, P_out);
     icp_amd_destroy(e);
     return rc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// whole path on several GPUs, single process, RCCL over xGMI
+// ------------------------------------------------------------------------------------------------
+namespace {
+// RCCL is loaded at run time so that libicp_amd.so has no link-time dependency on it (single-GPU users never load it).
+struct Rccl {
+    typedef void *comm_t;
+    int (*CommInitAll)(comm_t *, int, const int *) = nullptr;
+    int (*CommDestroy)(comm_t) = nullptr;
+    int (*AllGather)(const void *, void *, size_t, int, comm_t, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+    void *handle = nullptr;
+    static constexpr int kDouble = 8;  // ncclDouble / ncclFloat64 (rccl.h)
+    bool load()
+    {
+        if (handle) return true;
+        handle = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+        if (!handle) handle = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+        if (!handle) handle = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_LOCAL);
+        if (!handle) return false;
+        CommInitAll = (decltype(CommInitAll))dlsym(handle, "ncclCommInitAll");
+        CommDestroy = (decltype(CommDestroy))dlsym(handle, "ncclCommDestroy");
+        AllGather = (decltype(AllGather))dlsym(handle, "ncclAllGather");
+        GroupStart = (decltype(GroupStart))dlsym(handle, "ncclGroupStart");
+        GroupEnd = (decltype(GroupEnd))dlsym(handle, "ncclGroupEnd");
+        GetErrorString = (decltype(GetErrorString))dlsym(handle, "ncclGetErrorString");
+        return CommInitAll && CommDestroy && AllGather && GroupStart && GroupEnd && GetErrorString;
+    }
+};
+Rccl g_rccl;
+
+struct MultiRun {
+    std::vector<icp_amd_engine *> eng;
+    std::vector<double *> cov, cen;
+    std::vector<int> dev;
+    std::vector<Rccl::comm_t> comm;
+    ~MultiRun()
+    {
+        for (icp_amd_engine *e : eng) icp_amd_destroy(e);
+        for (size_t g = 0; g < dev.size(); ++g) {
+            (void)hipSetDevice(dev[g]);
+            if (g < cov.size() && cov[g]) (void)hipFree(cov[g]);
+            if (g < cen.size() && cen[g]) (void)hipFree(cen[g]);
+        }
+        for (Rccl::comm_t c : comm)
+            if (c) g_rccl.CommDestroy(c);
+    }
+};
+
+// in-place all-gather of the rank-major partial array of every device (slot g of device g's buffer is its contribution)
+int all_gather_partials(MultiRun &r, std::vector<double *> &buf, size_t per)
+{
+    const int G = (int)r.eng.size();
+    int rc = g_rccl.GroupStart();
+    for (int g = 0; g < G && rc == 0; ++g)
+        rc = g_rccl.AllGather(buf[g] + (size_t)g * per, buf[g], per, Rccl::kDouble, r.comm[g], r.eng[g]->stream);
+    const int rc2 = g_rccl.GroupEnd();
+    if (rc == 0) rc = rc2;
+    if (rc != 0) return fail(ICP_AMD_EHIP, "RCCL all-gather failed: %s", g_rccl.GetErrorString(rc));
+    return ICP_AMD_OK;
+}
+}  // namespace
+
+extern "C" int icp_amd_run_multi(const double *P, size_t n, const double *Q, size_t m, unsigned iters, int n_gpus, const int *devices,
+                                 double *P_out, icp_amd_trace *tr)
+{
+    if (!P || !Q || !P_out) return fail(ICP_AMD_EINVAL, "icp_amd_run_multi: NULL argument");
+    if (n == 0 || m == 0) return fail(ICP_AMD_EINVAL, "icp_amd_run_multi: empty cloud (n=%zu, m=%zu)", n, m);
+    const int avail = icp_amd_device_count();
+    if (avail <= 0) return fail(ICP_AMD_ENODEV, "no HIP device available; libicp_amd has no CPU fallback");
+    if (n_gpus < 1 || n_gpus > avail) return fail(ICP_AMD_EINVAL, "icp_amd_run_multi: n_gpus=%d but %d device(s) are visible", n_gpus, avail);
+    const int G = n_gpus;
+    if (G == 1 && !devices) return icp_amd_run(P, n, Q, m, iters, ICP_AMD_METHOD_SHARED_LOOP, P_out, tr);
+    if (!g_rccl.load()) return fail(ICP_AMD_EHIP, "icp_amd_run_multi: cannot load librccl.so (%s)", dlerror() ? dlerror() : "missing symbols");
+    MultiRun r;
+    for (int g = 0; g < G; ++g) r.dev.push_back(devices ? devices[g] : g);
+    const size_t cpr = icp_amd_chunks_per_rank(n, G), rpr = cpr * kChunk;
+    r.cov.assign(G, nullptr);
+    r.cen.assign(G, nullptr);
+    r.comm.assign(G, nullptr);
+    for (int g = 0; g < G; ++g) {
+        RCCHK(require_device(r.dev[g]));
+        HIPCHK(hipMalloc(&r.cov[g], (size_t)G * cpr * kCovW * sizeof(double)));
+        HIPCHK(hipMalloc(&r.cen[g], (size_t)G * cpr * kCenW * sizeof(double)));
+        HIPCHK(hipMemset(r.cov[g], 0, (size_t)G * cpr * kCovW * sizeof(double)));
+        HIPCHK(hipMemset(r.cen[g], 0, (size_t)G * cpr * kCenW * sizeof(double)));
+        icp_amd_options opt;
+        icp_amd_default_options(&opt);
+        opt.device = r.dev[g];
+        opt.rank = g;
+        opt.world = G;
+        opt.n_global = n;
+        opt.cov_gather = r.cov[g];
+        opt.cen_gather = r.cen[g];
+        icp_amd_engine *e = nullptr;
+        RCCHK(icp_amd_create(&e, &opt));
+        r.eng.push_back(e);
+    }
+    {
+        const int rc = g_rccl.CommInitAll(r.comm.data(), G, r.dev.data());
+        if (rc != 0) return fail(ICP_AMD_EHIP, "ncclCommInitAll failed: %s", g_rccl.GetErrorString(rc));
+    }
+    std::vector<size_t> lo(G), cnt(G);
+    for (int g = 0; g < G; ++g) {
+        lo[g] = (size_t)g * rpr < n ? (size_t)g * rpr : n;
+        cnt[g] = n - lo[g] < rpr ? n - lo[g] : rpr;
+        RCCHK(icp_amd_set_target(r.eng[g], Q, m));
+        RCCHK(icp_amd_set_source(r.eng[g], P + lo[g] * 3, cnt[g]));
+    }
+    for (int g = 0; g < G; ++g) RCCHK(icp_amd_step_begin(r.eng[g]));
+    RCCHK(all_gather_partials(r, r.cen, cpr * kCenW));
+    const bool tracing = tr && (tr->Pc || tr->idx || tr->cov || tr->S || tr->R || tr->t || tr->rms);
+    for (unsigned it = 0; it < iters; ++it) {
+        for (int g = 0; g < G; ++g) RCCHK(icp_amd_step_search(r.eng[g]));
+        RCCHK(all_gather_partials(r, r.cov, cpr * kCovW));
+        for (int g = 0; g < G; ++g) RCCHK(icp_amd_step_update(r.eng[g]));
+        RCCHK(all_gather_partials(r, r.cen, cpr * kCenW));
+        if (tracing) {
+            RCCHK(icp_amd_get_last(r.eng[0], tr->Pc ? tr->Pc + 3 * it : nullptr, nullptr, tr->cov ? tr->cov + 9 * it : nullptr,
+                                   tr->S ? tr->S + 3 * it : nullptr, tr->R ? tr->R + 9 * it : nullptr, tr->t ? tr->t + 3 * it : nullptr,
+                                   tr->rms ? tr->rms + it : nullptr));
+            if (tr->idx)
+                for (int g = 0; g < G; ++g)
+                    if (cnt[g])
+                        RCCHK(icp_amd_get_last(r.eng[g], nullptr, tr->idx + (size_t)it * n + lo[g], nullptr, nullptr, nullptr, nullptr, nullptr));
+        }
+    }
+    for (int g = 0; g < G; ++g)
+        if (cnt[g]) RCCHK(icp_amd_get_source(r.eng[g], P_out + lo[g] * 3));
+        else RCCHK(icp_amd_sync(r.eng[g]));
+    return ICP_AMD_OK;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -53,6 +53,8 @@ int main(int argc, char **argv)
         const size_t count = (size_t)std::stoul(argv[5]);
         runtime_assert(count > 0 && Pl % count == 0 && Ql % count == 0, "batch count must divide the row counts of both files");
         rc = icp_amd_run_batch(P.data(), Q.data(), count, Pl / count, Ql / count, nbiters, P_res.data(), nullptr, nullptr, nullptr, nullptr);
+    } else if (const char *g = std::getenv("ICP_AMD_GPUS"); g && std::atoi(g) > 1) {
+        rc = icp_amd_run_multi(P.data(), Pl, Q.data(), Ql, nbiters, std::atoi(g), nullptr, P_res.data(), nullptr);   // additive
     } else {
         rc = icp_amd_run(P.data(), Pl, Q.data(), Ql, nbiters, m, P_res.data(), nullptr);
     }

@@ -92,6 +92,14 @@ size_t      icp_amd_chunks_per_rank(size_t n_global, int world);
 int icp_amd_run(const double *P_xyz, size_t n, const double *Q_xyz, size_t m, unsigned iters,
                 int method, double *P_out, icp_amd_trace *trace);
 
+/* ---- whole path on several GPUs of one node, single process (no counterpart in the reference, which is
+ *      single-device).  The source rows are sharded over the `n_gpus` devices (devices == NULL: ordinals 0..n_gpus-1),
+ *      the target is replicated; per iteration the per-chunk partial sums are combined with two RCCL all-gathers over
+ *      xGMI (librccl.so is loaded at run time, only by this call), every device then sums all chunks in index order and
+ *      solves R, t redundantly.  Results are bit-identical to icp_amd_run for every n_gpus.  trace->idx: n per iteration. */
+int icp_amd_run_multi(const double *P_xyz, size_t n, const double *Q_xyz, size_t m, unsigned iters,
+                      int n_gpus, const int *devices, double *P_out, icp_amd_trace *trace);
+
 /* ---- persistent engine (replaces the allocation / H2D / loop / D2H plan of src/gpu/icp.cu:511-648) */
 int icp_amd_create(icp_amd_engine **out, const icp_amd_options *opt);
 int icp_amd_destroy(icp_amd_engine *e);

@@ -129,3 +129,18 @@ def test_bench_two_ranks_on_one_gpu_over_gloo():
     assert r1.returncode == 0, r1.stderr[-3000:]
     d1 = json.loads([ln for ln in r1.stdout.splitlines() if ln.startswith("{")][-1])
     assert d1["rms_last"] == d["rms_last"]
+
+
+def test_native_rccl_multi_entry_point():
+    """icp_amd_run_multi (single process, RCCL loaded at run time).  On this one-GPU box: a one-rank RCCL communicator
+    on an explicit device list exercises the load / init / in-place all-gather / teardown path, and must equal icp_amd_run;
+    asking for more GPUs than are visible is a clean error."""
+    P, Q = synth.make_pair(6000, 5000, seed=41)
+    want, trw = icp_amd.icp_gpu_optimized(P, Q, 3, trace=True)
+    got, trg = icp_amd.icp_gpu_multi(P, Q, 3, 1, devices=[0], trace=True)
+    assert np.array_equal(got, want)
+    for k in ("idx", "cov", "R", "t", "Pc"):
+        assert np.array_equal(trg[k], trw[k]), k
+    assert np.array_equal(icp_amd.icp_gpu_multi(P, Q, 3, 1), want)
+    with pytest.raises(icp_amd.IcpAmdError):
+        icp_amd.icp_gpu_multi(P, Q, 1, icp_amd.device_count() + 1)
