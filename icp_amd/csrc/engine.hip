@@ -266,36 +266,27 @@ static void choose_geometry(icp_amd_engine *e)
 
     const bool f32 = variant == kF32;
     const size_t cus = (size_t)e->cu_count;
-    const size_t tile = f32 ? 2048 : (size_t)kTileQ;
-    const size_t tiles = e->m_pad / tile;
-    const size_t want = 64 * cus;   // measured at 1M x 1M: 8 -> 16 splits (7.8k -> 15.6k workgroups) still gains 0.5 %
-    size_t max_splits = tiles / (f32 ? 2 : 4);  // a few LDS tiles per split at least
-    if (max_splits > 256) max_splits = 256;
-    if (max_splits < 1) max_splits = 1;
-    // most points per lane (fewest LDS reads per pair) that still yields >= 12 workgroups per CU
-    const int ppl_hi = f32 ? 8 : 4, ppl_lo = f32 ? 2 : 1;
-    int ppl = ppl_lo;
-    size_t splits = 1, best_wgs = 0;
-    for (int cand = ppl_hi; cand >= ppl_lo; cand /= 2) {
-        const size_t ptiles = e->n_pad / ((size_t)kWG * cand);
-        size_t sp = (want + ptiles - 1) / ptiles;
-        if (sp > max_splits) sp = max_splits;
-        if (sp < 1) sp = 1;
-        const size_t wgs = ptiles * sp;
-        if (wgs >= (f32 ? 8 : 12) * cus) { ppl = cand; splits = sp; best_wgs = wgs; break; }
-        if (wgs > best_wgs) { ppl = cand; splits = sp; best_wgs = wgs; }
-    }
+    // Source points per lane: more points share one LDS read of a target (the big clouds are LDS-read bound below 8 for
+    // the fp32 filter, below 4 for fp64), fewer give more workgroups to spread a small cloud over the chip.
+    int ppl = f32 ? (e->n_pad <= 32768 ? 2 : e->n_pad <= 524288 ? 4 : 8) : (e->n_pad <= 32768 ? 2 : 4);
     const int env_ppl = env_int("ICP_AMD_PPL", 0);
-    if ((env_ppl == 1 && !f32) || env_ppl == 2 || env_ppl == 4 || (env_ppl == 8 && f32)) {
-        ppl = env_ppl;
-        const size_t ptiles = e->n_pad / ((size_t)kWG * ppl);
-        splits = (want + ptiles - 1) / ptiles;
-        if (splits > max_splits) splits = max_splits;
-    }
+    if ((env_ppl == 1 && !f32) || env_ppl == 2 || env_ppl == 4 || (env_ppl == 8 && f32)) ppl = env_ppl;
+    // Workgroups: each one pays a fixed price (its seed blocks, its tile loads, one record per source point and split
+    // for the merge), while too few leave CUs idle at the tail -- the optimum grows like sqrt(pairs).  Measured on
+    // MI355X (tools/sweep_small.py, profiles/r1_sweep_small.txt): 520 workgroups at 20k x 20k, 1k at 48k, 2-4k at
+    // 100k, 8k at 300k, 8-16k at 1M x 1M (flat); never fewer than two per CU.
+    const size_t scan_blocks = search_scan_rows(e->m) / kSplitGran;
+    const double pairs = (double)e->n_pad * (double)search_scan_rows(e->m);
+    size_t want = (size_t)(sqrt(pairs) / 40.0 * ((double)cus / 256.0));
+    if (want < 2 * cus) want = 2 * cus;
+    if (want > 64 * cus) want = 64 * cus;
+    const size_t xblocks = e->n_pad / ((size_t)kWG * ppl);
+    size_t splits = (want + xblocks - 1) / xblocks;
+    if (splits > 1024) splits = 1024;
     if (e->opt.q_splits > 0) splits = (size_t)e->opt.q_splits;
     splits = (size_t)env_int("ICP_AMD_QSPLITS", (int)splits);
     if (splits < 1) splits = 1;
-    if (splits > tiles) splits = tiles;
+    if (splits > scan_blocks) splits = scan_blocks;
     e->ppl = ppl;
     e->q_splits = (int)splits;
     // an un-seeded search re-learns its running minimum in every split: keep the first iteration coarser
@@ -905,9 +896,9 @@ extern "C" int icp_amd_correspondences(const double *P, size_t n, const double P
     HIPCHK(pc.alloc(3 * sizeof(double)));
     HIPCHK(hipMemcpyAsync(pc.p, Pc, 3 * sizeof(double), hipMemcpyHostToDevice, s));
     const bool f32 = search_variant == ICP_AMD_SEARCH_F32;
-    const size_t tiles = m_pad / (f32 ? 2048 : kTileQ);
+    const size_t max_splits = search_scan_rows(m) / kSplitGran;
     if (q_splits < 1) q_splits = 1;
-    if ((size_t)q_splits > tiles) q_splits = (int)tiles;
+    if ((size_t)q_splits > max_splits) q_splits = (int)max_splits;
     int ppl = env_int("ICP_AMD_PPL", 4);
     if (ppl != 1 && ppl != 2 && ppl != 4 && ppl != 8) ppl = 4;
     if (f32 && ppl == 1) ppl = 2;

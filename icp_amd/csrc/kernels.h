@@ -15,6 +15,7 @@ constexpr int kCenW    = 3;      // doubles per centroid partial
 
 enum SearchVariant { kExact = 1, kFma = 2, kF32 = 3 };
 constexpr size_t kPadRows = 2048;  // clouds are padded to this many rows (covers every kernel's tile)
+constexpr size_t kSplitGran = 64;  // target splits are whole multiples of this many targets (>= every cb, even)
 
 struct Soa3 {            // device SoA view of a cloud
     double *x, *y, *z;
@@ -28,6 +29,11 @@ hipError_t finalize_centroid(hipStream_t s, const double *partial, size_t count,
 // AoS -> SoA, padded rows [n, n_pad) set to `pad`.  If c3 != nullptr subtracts c3[k] (the centring of Q).
 hipError_t aos_to_soa(hipStream_t s, const double *aos, size_t n, size_t n_pad, const double *c3, double pad, Soa3 out);
 hipError_t soa_to_aos(hipStream_t s, Soa3 in, size_t n, double *aos);
+
+// Split geometry of both search kernels: targets [0, search_scan_rows(m)) in q_splits pieces of
+// search_rows_per_split(m, q_splits) targets each (trailing pieces may be empty; their records read (inf, ~0) or the seed).
+size_t search_scan_rows(size_t m);
+size_t search_rows_per_split(size_t m, int q_splits);
 
 // Brute-force nearest neighbour: for source row i (centred on the fly with pc) and target split y,
 // (key, idx) of the lexicographically smallest (sqrt(sqrt(d^2)), j) over the split's target range.

@@ -153,14 +153,43 @@ __device__ __forceinline__ double d2_fused(double ax, double ay, double az, doub
 __device__ __forceinline__ double key_of(double d2) { return sqrt(sqrt(d2)); }
 
 // Slow path, entered by the lanes whose running minimum dropped inside the last block of CB targets:
-// re-evaluates the block un-fused, in target order, and updates the lexicographic best (key, index).
-// Invariant on exit: every target not yet scanned that can still beat (bk, bj) has d^2 < bd
+// re-evaluates the block un-fused and updates the lexicographic best (key, index) exactly as a scan in target order
+// would.  Invariant on exit: every target not yet scanned that can still beat (bk, bj) has d^2 < bd
 // (key is a monotone function of d^2; targets arrive in ascending index order; a seed taken from the
 // previous iteration may have a higher index than targets still to come, hence the index compare).
+//
+// The in-order scan (one branch and possibly two square roots per target, loads not overlapped) is kept for the
+// rare hard case only.  First a branch-free pass finds the smallest d^2 of the block (dm, first index um) and the
+// second smallest (d2nd) with the loads of eight targets in flight.  dm >= bd: a false alarm of the pre-filter,
+// nothing changes.  d2nd outside the tie band of dm (the fourth root merges fewer than 16 neighbouring doubles, so a
+// d^2 more than 2^-48 above dm has a strictly larger key): every other target of the block loses to um on the key,
+// and the in-order scan would end with best = lexmin(best, (key(dm), um)), bd = dm -- computed directly.
 template <int CB>
 __device__ __forceinline__ void rescan_block(double ax, double ay, double az, const double *sx, const double *sy,
-                                             const double *sz, int j0, unsigned jglobal, double &bd, double &bk, uint32_t &bj)
+                                             const double *sz, int j0, unsigned jglobal, double &bd, double &bk, uint32_t &bj,
+                                             double &dbest)
 {
+    double dm = INFINITY, d2nd = INFINITY;
+    int um = 0;
+#pragma unroll 8
+    for (int u = 0; u < CB; ++u) {
+        const double d = d2_exact(ax, ay, az, sx[j0 + u], sy[j0 + u], sz[j0 + u]);
+        d2nd = __builtin_fmin(d2nd, __builtin_fmax(d, dm));
+        um = (d < dm) ? u : um;
+        dm = __builtin_fmin(dm, d);
+    }
+    if (!(dm < bd)) return;
+    if (d2nd > __builtin_fma(dm, 1.0 + 0x1p-48, 1e-300)) {
+        bd = dm;
+        const double key = key_of(dm);
+        const uint32_t j = jglobal + (unsigned)um;
+        if (key < bk || (key == bk && j < bj)) {
+            bk = key;
+            bj = j;
+            dbest = dm;   // exact d^2 of the current best
+        }
+        return;
+    }
 #pragma unroll 1
     for (int u = 0; u < CB; ++u) {
         const double d = d2_exact(ax, ay, az, sx[j0 + u], sy[j0 + u], sz[j0 + u]);
@@ -171,9 +200,42 @@ __device__ __forceinline__ void rescan_block(double ax, double ay, double az, co
             if (key < bk || (key == bk && j < bj)) {
                 bk = key;
                 bj = j;
+                dbest = d;
             }
         }
     }
+}
+
+// Seeding (both search kernels).  The previous iteration's correspondence js is a legitimate candidate; starting from
+// it makes the running minimum tight from the first target on.  Two details keep that exact and cheap:
+//  * targets with the SAME key and a lower index must still get through: their d^2 lies within a few ulp of the seed's
+//    (the fourth root merges at most ~8 neighbouring doubles), so the running bound carries a 2^-48 margin;
+//  * with that margin the seed itself would trip the event check of its own block -- once per source point per
+//    launch, i.e. in nearly every block of a wave when the target range is short.  So the seed's block (if it lies in
+//    this workgroup's target range) is evaluated exactly up front, by every lane for its own seed in parallel, and
+//    skipped by the event check later (sblk).
+// Returns the bound bd to start from; bk/bj are set to the best of {seed, seed's block}.
+template <int CB>
+__device__ __forceinline__ double seed_init(double ax, double ay, double az, const double *__restrict__ qx,
+                                            const double *__restrict__ qy, const double *__restrict__ qz, uint32_t js, unsigned m,
+                                            unsigned q0, unsigned q1, double &bk, uint32_t &bj, uint32_t &sblk)
+{
+    bk = INFINITY;  // oracle: min_dist = DBL_MAX on the key, i.e. any finite d^2 is accepted
+    bj = 0xFFFFFFFFu;
+    sblk = 0xFFFFFFFFu;
+    if (js >= m) return INFINITY;
+    const double d = d2_exact(ax, ay, az, qx[js], qy[js], qz[js]);
+    if (!(d < INFINITY)) return INFINITY;
+    bk = key_of(d);
+    bj = js;
+    double dbest = d;
+    if (js >= q0 && js < q1) {
+        const unsigned jb = (js / CB) * CB;
+        double bd = __builtin_fma(d, 1.0 + 0x1p-48, 1e-300);
+        rescan_block<CB>(ax, ay, az, qx + jb, qy + jb, qz + jb, 0, jb, bd, bk, bj, dbest);
+        sblk = js / CB;
+    }
+    return __builtin_fma(dbest, 1.0 + 0x1p-48, 1e-300);
 }
 
 // grid = (n_pad / (256*PPL), q_splits).  Every lane owns PPL source points (kept in registers, centred
@@ -195,6 +257,7 @@ struct LaneSearch {
     double thr[PPL];                   // filter-space image of bd
     double bd[PPL], bk[PPL];
     uint32_t bj[PPL];
+    uint32_t sblk[PPL];                // block (global target index / CB) already evaluated by seed_init, or ~0
 };
 
 template <int MODE>
@@ -203,27 +266,6 @@ __device__ __forceinline__ double filter_threshold(double bd)
     // fused and un-fused d^2 agree within (1+u)^6: any target with exact d^2 < bd has a fused d^2 below
     // bd*(1+2^-49) (+ a subnormal-range guard)
     return (MODE == kFma) ? __builtin_fma(bd, 1.0 + 0x1p-49, 1e-300) : bd;
-}
-
-// Start of a scan for slot s: nothing seen, or seeded with target js (coordinates sx,sy,sz; js >= m means none).
-template <int PPL, int MODE>
-__device__ __forceinline__ void lane_init(LaneSearch<PPL> &L, int s, bool seeded, uint32_t js, double sx, double sy, double sz)
-{
-    L.bd[s] = INFINITY;  // oracle: min_dist = DBL_MAX on the key, i.e. any finite d^2 is accepted
-    L.bk[s] = INFINITY;
-    L.bj[s] = 0xFFFFFFFFu;
-    if (seeded) {
-        const double d = d2_exact(L.ax[s], L.ay[s], L.az[s], sx, sy, sz);
-        if (d < INFINITY) {
-            L.bk[s] = key_of(d);
-            L.bj[s] = js;
-            // targets with the same key and a lower index must still get through: their d^2 lies within a
-            // few ulp of d (the fourth root merges at most ~8 neighbouring doubles), far inside this margin
-            L.bd[s] = __builtin_fma(d, 1.0 + 0x1p-48, 1e-300);
-        }
-    }
-    L.thr[s] = filter_threshold<MODE>(L.bd[s]);
-    L.m_[s] = __builtin_fmin(L.thr[s], INFINITY);
 }
 
 // Scan `count` (multiple of CB) targets held in LDS as SoA; jbase = global index of target 0 of the tile.
@@ -242,14 +284,19 @@ __device__ __forceinline__ void scan_tile(LaneSearch<PPL> &L, const double *sx, 
                 L.m_[s] = __builtin_fmin(L.m_[s], d);
             }
         }
+        const unsigned blk = (jbase + (unsigned)j0) / CB;
         bool ev = false;
 #pragma unroll
-        for (int s = 0; s < PPL; ++s) ev |= (L.m_[s] < L.thr[s]);
+        for (int s = 0; s < PPL; ++s) {
+            if (blk == L.sblk[s]) L.m_[s] = L.thr[s];   // the seed's own block was evaluated exactly by seed_init
+            ev |= (L.m_[s] < L.thr[s]);
+        }
         if (ev) {
 #pragma unroll
             for (int s = 0; s < PPL; ++s) {
                 if (L.m_[s] < L.thr[s]) {
-                    rescan_block<CB>(L.ax[s], L.ay[s], L.az[s], sx, sy, sz, j0, jbase + (unsigned)j0, L.bd[s], L.bk[s], L.bj[s]);
+                    double dbest;
+                    rescan_block<CB>(L.ax[s], L.ay[s], L.az[s], sx, sy, sz, j0, jbase + (unsigned)j0, L.bd[s], L.bk[s], L.bj[s], dbest);
                     L.thr[s] = filter_threshold<MODE>(L.bd[s]);
                     L.m_[s] = __builtin_fmin(L.thr[s], INFINITY);
                 }
@@ -262,7 +309,7 @@ template <int PPL, int MODE, int CB>
 __global__ __launch_bounds__(kWG) void search_kernel(const double *__restrict__ px, const double *__restrict__ py,
                                                      const double *__restrict__ pz, const double *__restrict__ pc,
                                                      const double *__restrict__ qx, const double *__restrict__ qy,
-                                                     const double *__restrict__ qz, unsigned n_pad, unsigned m, unsigned m_pad,
+                                                     const double *__restrict__ qz, unsigned n_pad, unsigned m, unsigned m_scan,
                                                      unsigned q_per_split, const uint32_t *__restrict__ idx_prev,
                                                      double *__restrict__ out_key, uint32_t *__restrict__ out_idx)
 {
@@ -270,6 +317,9 @@ __global__ __launch_bounds__(kWG) void search_kernel(const double *__restrict__ 
     const unsigned tid = threadIdx.x;
     const unsigned base = blockIdx.x * (kWG * PPL) + tid;
     const double c0 = pc[0], c1 = pc[1], c2 = pc[2];
+    // this workgroup's target range [q0, q1): m_scan = m rounded up to kSplitGran (the rest of the padding is never read)
+    const unsigned q0 = blockIdx.y * q_per_split;
+    const unsigned q1 = (q0 + q_per_split < m_scan) ? (q0 + q_per_split) : m_scan;
 
     LaneSearch<PPL> L;
 #pragma unroll
@@ -277,30 +327,22 @@ __global__ __launch_bounds__(kWG) void search_kernel(const double *__restrict__ 
         L.ax[s] = px[base + s * kWG] - c0;
         L.ay[s] = py[base + s * kWG] - c1;
         L.az[s] = pz[base + s * kWG] - c2;
-        uint32_t js = 0xFFFFFFFFu;
-        double sx = 0, sy = 0, sz = 0;
-        if (idx_prev) {
-            js = idx_prev[base + s * kWG];
-            if (js < m) {
-                sx = qx[js];
-                sy = qy[js];
-                sz = qz[js];
-            }
-        }
-        lane_init<PPL, MODE>(L, s, js < m, js, sx, sy, sz);
+        const uint32_t js = idx_prev ? idx_prev[base + s * kWG] : 0xFFFFFFFFu;
+        L.bd[s] = seed_init<CB>(L.ax[s], L.ay[s], L.az[s], qx, qy, qz, js, m, q0, q1, L.bk[s], L.bj[s], L.sblk[s]);
+        L.thr[s] = filter_threshold<MODE>(L.bd[s]);
+        L.m_[s] = __builtin_fmin(L.thr[s], INFINITY);
     }
 
-    const unsigned q0 = blockIdx.y * q_per_split;
-    const unsigned q1 = (q0 + q_per_split < m_pad) ? (q0 + q_per_split) : m_pad;
     for (unsigned t0 = q0; t0 < q1; t0 += kTileQ) {
+        const int cnt = (q1 - t0 < (unsigned)kTileQ) ? (int)(q1 - t0) : kTileQ;   // multiple of kSplitGran
         __syncthreads();
-        for (int k = tid; k < kTileQ; k += kWG) {
+        for (int k = tid; k < cnt; k += kWG) {
             sq[0][k] = qx[t0 + k];
             sq[1][k] = qy[t0 + k];
             sq[2][k] = qz[t0 + k];
         }
         __syncthreads();
-        scan_tile<PPL, MODE, CB>(L, sq[0], sq[1], sq[2], kTileQ, t0);
+        scan_tile<PPL, MODE, CB>(L, sq[0], sq[1], sq[2], cnt, t0);
     }
     const size_t o = (size_t)blockIdx.y * n_pad + base;
 #pragma unroll
@@ -373,7 +415,7 @@ __global__ __launch_bounds__(kWG) void search_f32_kernel(const double *__restric
                                                          const double *__restrict__ pz, const double *__restrict__ pc,
                                                          const double *__restrict__ qx, const double *__restrict__ qy,
                                                          const double *__restrict__ qz, const QRec *__restrict__ qrec, double qmax,
-                                                         unsigned n_pad, unsigned m, unsigned m_pad, unsigned q_per_split,
+                                                         unsigned n_pad, unsigned m, unsigned m_scan, unsigned q_per_split,
                                                          const uint32_t *__restrict__ idx_prev, double *__restrict__ out_key,
                                                          uint32_t *__restrict__ out_idx)
 {
@@ -385,7 +427,9 @@ __global__ __launch_bounds__(kWG) void search_f32_kernel(const double *__restric
     float fx[PPL], fy[PPL], fz[PPL], ms[PPL], thr[PPL];
     double off[PPL];   // E - |p|^2 (1 - 2^-50): threshold = bd (1+2^-50) + off
     double bd[PPL], bk[PPL];
-    uint32_t bj[PPL];
+    uint32_t bj[PPL], sblk[PPL];
+    const unsigned q0 = blockIdx.y * q_per_split;
+    const unsigned q1 = (q0 + q_per_split < m_scan) ? (q0 + q_per_split) : m_scan;
 #pragma unroll
     for (int s = 0; s < PPL; ++s) {
         const double ax = px[base + s * kWG] - c0, ay = py[base + s * kWG] - c1, az = pz[base + s * kWG] - c2;
@@ -396,31 +440,18 @@ __global__ __launch_bounds__(kWG) void search_f32_kernel(const double *__restric
         const double E = 0x1p-24 * (11.0 * sqrt(pn) * qmax + 5.0 * qmax * qmax) + 1e-35;
         // outside the range where the fp32 bound is meaningful the lane simply always takes the exact path
         off[s] = (pn < 1e30) ? (E - pn) + pn * 0x1p-50 : INFINITY;
-        bd[s] = INFINITY;
-        bk[s] = INFINITY;
-        bj[s] = 0xFFFFFFFFu;
-        if (idx_prev) {
-            const uint32_t js = idx_prev[base + s * kWG];
-            if (js < m) {
-                const double d = d2_exact(ax, ay, az, qx[js], qy[js], qz[js]);
-                if (d < INFINITY) {
-                    bk[s] = key_of(d);
-                    bj[s] = js;
-                    bd[s] = __builtin_fma(d, 1.0 + 0x1p-48, 1e-300);
-                }
-            }
-        }
+        const uint32_t js = idx_prev ? idx_prev[base + s * kWG] : 0xFFFFFFFFu;
+        bd[s] = seed_init<CB>(ax, ay, az, qx, qy, qz, js, m, q0, q1, bk[s], bj[s], sblk[s]);
         thr[s] = f32_above(__builtin_fma(bd[s], 1.0 + 0x1p-50, off[s]));
         ms[s] = thr[s];
     }
 
-    const unsigned q0 = blockIdx.y * q_per_split;
-    const unsigned q1 = (q0 + q_per_split < m_pad) ? (q0 + q_per_split) : m_pad;
     for (unsigned t0 = q0; t0 < q1; t0 += kTileQF) {
+        const int cnt = (q1 - t0 < (unsigned)kTileQF) ? (int)(q1 - t0) : kTileQF;   // multiple of kSplitGran
         __syncthreads();
-        for (int k = tid; k < kTileQF; k += kWG) st[k] = qrec[t0 + k];
+        for (int k = tid; k < cnt; k += kWG) st[k] = qrec[t0 + k];
         __syncthreads();
-        for (int j0 = 0; j0 < kTileQF; j0 += CB) {
+        for (int j0 = 0; j0 < cnt; j0 += CB) {
             // software-pipelined over pairs of targets: the LDS reads of pair u+1 are in flight while pair u is computed
             const f32x2 *pr = (const f32x2 *)&st[j0];
             f32x2 X = pr[0], Y = pr[1], Z = pr[2], W = pr[3];
@@ -455,9 +486,13 @@ __global__ __launch_bounds__(kWG) void search_f32_kernel(const double *__restric
                 }
                 X = Xn; Y = Yn; Z = Zn; W = Wn;
             }
+            const unsigned blk = (t0 + (unsigned)j0) / CB;
             bool ev = false;
 #pragma unroll
-            for (int s = 0; s < PPL; ++s) ev |= (ms[s] < thr[s]);
+            for (int s = 0; s < PPL; ++s) {
+                if (blk == sblk[s]) ms[s] = thr[s];   // the seed's own block was evaluated exactly by seed_init
+                ev |= (ms[s] < thr[s]);
+            }
             if (ev) {
 #pragma unroll
                 for (int s = 0; s < PPL; ++s) {
@@ -465,7 +500,8 @@ __global__ __launch_bounds__(kWG) void search_f32_kernel(const double *__restric
                         // exact re-evaluation of the block in fp64 from the source arrays (rare: reloaded, not kept in registers)
                         const double ax = px[base + s * kWG] - c0, ay = py[base + s * kWG] - c1, az = pz[base + s * kWG] - c2;
                         const unsigned jg = t0 + (unsigned)j0;
-                        rescan_block<CB>(ax, ay, az, qx + jg, qy + jg, qz + jg, 0, jg, bd[s], bk[s], bj[s]);
+                        double dbest;
+                        rescan_block<CB>(ax, ay, az, qx + jg, qy + jg, qz + jg, 0, jg, bd[s], bk[s], bj[s], dbest);
                         thr[s] = f32_above(__builtin_fma(bd[s], 1.0 + 0x1p-50, off[s]));
                         ms[s] = thr[s];
                     }
@@ -977,19 +1013,28 @@ hipError_t soa_to_aos(hipStream_t s, Soa3 in, size_t n, double *aos)
     return hipGetLastError();
 }
 
+// Split geometry shared by both search kernels: the scanned range is m rounded up to kSplitGran targets (pads inside
+// it compare as +inf), cut into q_splits pieces of a whole number of kSplitGran-blocks; trailing pieces may be empty.
+size_t search_scan_rows(size_t m) { return (m + kSplitGran - 1) / kSplitGran * kSplitGran; }
+size_t search_rows_per_split(size_t m, int q_splits)
+{
+    const size_t blocks = search_scan_rows(m) / kSplitGran;
+    return (blocks + (size_t)q_splits - 1) / (size_t)q_splits * kSplitGran;
+}
+
 template <int PPL, int CB>
 static hipError_t search_launch(hipStream_t s, int variant, Soa3 P, size_t n_pad, const double *pc, Soa3 Qz, size_t m,
                                 size_t m_pad, int q_splits, const uint32_t *idx_prev, double *out_key, uint32_t *out_idx)
 {
-    const size_t tiles = m_pad / kTileQ;
-    const unsigned q_per_split = (unsigned)(((tiles + q_splits - 1) / q_splits) * kTileQ);
+    const unsigned m_scan = (unsigned)search_scan_rows(m);
+    const unsigned q_per_split = (unsigned)search_rows_per_split(m, q_splits);
     dim3 grid((unsigned)(n_pad / (kWG * PPL)), (unsigned)q_splits);
     if (variant == kFma)
         search_kernel<PPL, kFma, CB><<<grid, kWG, 0, s>>>(P.x, P.y, P.z, pc, Qz.x, Qz.y, Qz.z, (unsigned)n_pad, (unsigned)m,
-                                                          (unsigned)m_pad, q_per_split, idx_prev, out_key, out_idx);
+                                                          m_scan, q_per_split, idx_prev, out_key, out_idx);
     else
         search_kernel<PPL, kExact, CB><<<grid, kWG, 0, s>>>(P.x, P.y, P.z, pc, Qz.x, Qz.y, Qz.z, (unsigned)n_pad, (unsigned)m,
-                                                            (unsigned)m_pad, q_per_split, idx_prev, out_key, out_idx);
+                                                            m_scan, q_per_split, idx_prev, out_key, out_idx);
     return hipGetLastError();
 }
 
@@ -1019,11 +1064,11 @@ template <int PPL, int CB, bool PK>
 static hipError_t search_f32_launch(hipStream_t s, Soa3 P, size_t n_pad, const double *pc, Soa3 Qz, const void *qrec, double qmax,
                                     size_t m, size_t m_pad, int q_splits, const uint32_t *idx_prev, double *out_key, uint32_t *out_idx)
 {
-    const size_t tiles = m_pad / kTileQF;
-    const unsigned q_per_split = (unsigned)(((tiles + q_splits - 1) / q_splits) * kTileQF);
+    const unsigned m_scan = (unsigned)search_scan_rows(m);
+    const unsigned q_per_split = (unsigned)search_rows_per_split(m, q_splits);
     dim3 grid((unsigned)(n_pad / (kWG * PPL)), (unsigned)q_splits);
     search_f32_kernel<PPL, CB, PK><<<grid, kWG, 0, s>>>(P.x, P.y, P.z, pc, Qz.x, Qz.y, Qz.z, (const QRec *)qrec, qmax, (unsigned)n_pad,
-                                                    (unsigned)m, (unsigned)m_pad, q_per_split, idx_prev, out_key, out_idx);
+                                                    (unsigned)m, m_scan, q_per_split, idx_prev, out_key, out_idx);
     return hipGetLastError();
 }
 

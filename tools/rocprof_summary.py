@@ -38,8 +38,32 @@ def pmc(db):
             print("    %-28s %22.1f  (per dispatch %.1f)" % (cn, acc[k][cn], acc[k][cn] / n))
 
 
+def timeline(db, skip=0.5):
+    """Average kernel duration and the gap before each kernel, over the steady-state part of the trace."""
+    c = sqlite3.connect(db)
+    cols = [r[1] for r in c.execute("pragma table_info(kernels)")]
+    if not cols:
+        print("views:", [r[0] for r in c.execute("select name from sqlite_master")])
+        return
+    rows = list(c.execute("select name,start,end from kernels order by start"))
+    rows = rows[int(len(rows) * skip):]
+    dur = defaultdict(list)
+    gap = defaultdict(list)
+    for i, (name, s, e) in enumerate(rows):
+        k = short(name)[:44]
+        dur[k].append(e - s)
+        if i:
+            gap[k].append(s - rows[i - 1][2])
+    print("%-44s %6s %10s %14s" % ("kernel", "calls", "avg_us", "gap_before_us"))
+    for k in dur:
+        print("%-44s %6d %10.2f %14.2f" % (k, len(dur[k]), sum(dur[k]) / len(dur[k]) / 1e3, sum(gap[k]) / max(1, len(gap[k])) / 1e3))
+    print("span_us %.1f  kernels %d" % ((rows[-1][2] - rows[0][1]) / 1e3, len(rows)))
+
+
 if __name__ == "__main__":
-    if sys.argv[1] == "--pmc":
+    if sys.argv[1] == "--timeline":
+        timeline(sys.argv[2])
+    elif sys.argv[1] == "--pmc":
         pmc(sys.argv[2])
     else:
         stats(sys.argv[1])
