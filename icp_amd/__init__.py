@@ -159,7 +159,7 @@ class Engine:
         a, b, c, d = C.c_int(), C.c_int(), C.c_int(), C.c_int()
         check(lib().icp_amd_search_geometry(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
         return dict(points_per_lane=a.value, q_splits=b.value, workgroups=c.value,
-                    variant={1: "exact", 2: "fma", 3: "f32"}.get(d.value, str(d.value)))
+                    variant={1: "exact", 2: "fma", 3: "f32", 4: "grid"}.get(d.value, str(d.value)))
 
 
 class Batch:

@@ -8,7 +8,7 @@ LIB_PATH = os.path.join(_HERE, "libicp_amd.so")
 
 OK, EINVAL, ENODEV, EHIP, ENOMEM, EIO, ESTATE = 0, -1, -2, -3, -4, -5, -6
 METHODS = {"-shared-loop": 0, "-shared": 1, "-loop": 2, "-batch": 3}
-SEARCH = {"auto": 0, "exact": 1, "fma": 2, "f32": 3}
+SEARCH = {"auto": 0, "exact": 1, "fma": 2, "f32": 3, "grid": 4}
 
 
 class Trace(C.Structure):

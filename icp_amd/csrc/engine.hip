@@ -102,6 +102,8 @@ struct icp_amd_engine {
     unsigned long long *qmax2_dev = nullptr;
     double qmax = 0.0;          // sqrt(max |q|^2) of the centred target
     bool f32_ok = false;        // the fp32 error bound is meaningful for this target's range
+    Grid grid;                  // uniform grid over Qz (search variant GRID); built on first use per target
+    bool grid_built = false;
 
     // source (local rows)
     size_t n = 0, n_pad = 0, n_global = 0;
@@ -184,6 +186,7 @@ extern "C" int icp_amd_destroy(icp_amd_engine *e)
     for (hipEvent_t ev : e->ev) (void)hipEventDestroy(ev);
     free_dev(e->q_store); free_dev(e->qc); free_dev(e->qrec); free_dev(e->qmax2_dev); free_dev(e->p_store); free_dev(e->pc); free_dev(e->stage);
     free_dev(e->keys); free_dev(e->idxs); free_dev(e->idx); free_dev(e->rec);
+    grid_free(&e->grid);
     if (e->own_part) { free_dev(e->cov_part); free_dev(e->cen_part); }
     if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
@@ -244,9 +247,26 @@ extern "C" int icp_amd_set_target(icp_amd_engine *e, const double *Q, size_t m)
     e->f32_ok = (qmax2 == qmax2) && qmax2 > 1e-30 && qmax2 < 1e30;
     e->qmax = e->f32_ok ? sqrt(qmax2) : 0.0;
     e->have_target = true;
+    grid_free(&e->grid);
+    e->grid_built = false;
     e->have_prev = false;                       // correspondences into the previous target are no seed for this one
     if (e->have_source) RCCHK(plan_search(e));  // the variant and the splits depend on the target
     return ICP_AMD_OK;
+}
+
+// GRID evaluates only the targets near each source point (grid.hip); the others are brute force over all pairs.
+static int requested_variant(const icp_amd_engine *e)
+{
+    int variant = e->opt.search == ICP_AMD_SEARCH_EXACT  ? kExact
+                  : e->opt.search == ICP_AMD_SEARCH_FMA  ? kFma
+                  : e->opt.search == ICP_AMD_SEARCH_GRID ? kGrid
+                                                         : kF32;
+    const char *sv = getenv("ICP_AMD_SEARCH");
+    if (sv && !strcmp(sv, "fma")) variant = kFma;
+    if (sv && !strcmp(sv, "exact")) variant = kExact;
+    if (sv && !strcmp(sv, "f32")) variant = kF32;
+    if (sv && !strcmp(sv, "grid")) variant = kGrid;
+    return variant;
 }
 
 // Launch geometry of the search kernel: enough workgroups to load every CU several times over, without
@@ -256,11 +276,8 @@ static void choose_geometry(icp_amd_engine *e)
     // Every variant returns identical indices (each candidate is re-evaluated in the oracle's un-fused fp64 sequence);
     // they differ in what the fast path costs per pair: EXACT 9.1 fp64 VALU instructions, FMA 7.1 fp64, F32 3.5 fp32.
     // AUTO = F32, which degrades to FMA when the target's range makes the fp32 bound meaningless.
-    int variant = e->opt.search == ICP_AMD_SEARCH_EXACT ? kExact : e->opt.search == ICP_AMD_SEARCH_FMA ? kFma : kF32;
-    const char *sv = getenv("ICP_AMD_SEARCH");
-    if (sv && !strcmp(sv, "fma")) variant = kFma;
-    if (sv && !strcmp(sv, "exact")) variant = kExact;
-    if (sv && !strcmp(sv, "f32")) variant = kF32;
+    int variant = requested_variant(e);
+    if (variant == kGrid && !(e->grid_built && e->grid.ok)) variant = kF32;   // non-finite target coordinates
     if (variant == kF32 && !e->f32_ok) variant = kFma;
     e->variant = variant;
 
@@ -287,6 +304,7 @@ static void choose_geometry(icp_amd_engine *e)
     splits = (size_t)env_int("ICP_AMD_QSPLITS", (int)splits);
     if (splits < 1) splits = 1;
     if (splits > scan_blocks) splits = scan_blocks;
+    if (variant == kGrid) { ppl = 1; splits = 1; }   // one lane per source point, one (key, idx) record each
     e->ppl = ppl;
     e->q_splits = (int)splits;
     // an un-seeded search re-learns its running minimum in every split: keep the first iteration coarser
@@ -301,6 +319,10 @@ static void choose_geometry(icp_amd_engine *e)
 // Launch geometry + the per-split (key, idx) scratch it needs; re-run whenever the source or the target changes.
 static int plan_search(icp_amd_engine *e)
 {
+    if (requested_variant(e) == kGrid && !e->grid_built) {
+        HIPCHK(grid_build(e->stream, e->Qz, e->m, &e->grid));
+        e->grid_built = true;
+    }
     choose_geometry(e);
     const size_t need = (size_t)e->q_splits * e->n_pad;
     if (need > e->split_cap) {
@@ -428,7 +450,9 @@ extern "C" int icp_amd_step_search(icp_amd_engine *e)
         }
         const bool seed = e->have_prev && env_int("ICP_AMD_SEED", 1) != 0;
         const int splits = seed ? e->q_splits : e->q_splits_first;
-        if (e->variant == kF32)
+        if (e->variant == kGrid)
+            HIPCHK(search_grid(e->stream, e->P, e->n, e->pc, e->grid, e->Qz, e->m, seed ? e->idx : nullptr, e->keys, e->idxs));
+        else if (e->variant == kF32)
             HIPCHK(search_f32(e->stream, e->ppl, e->cb, e->P, e->n_pad, e->pc, e->Qz, e->qrec, e->qmax, e->m, e->m_pad, splits,
                               seed ? e->idx : nullptr, e->keys, e->idxs));
         else
@@ -910,7 +934,16 @@ extern "C" int icp_amd_correspondences(const double *P, size_t n, const double P
     const int variant = search_variant == ICP_AMD_SEARCH_FMA ? kFma : kExact;
     int cb = env_int("ICP_AMD_CB", 32);
     if (cb != 8 && cb != 16 && cb != 32) cb = 32;
-    if (f32) {
+    struct GridHolder { Grid g; ~GridHolder() { grid_free(&g); } } gh;
+    bool grid = search_variant == ICP_AMD_SEARCH_GRID;
+    if (grid) {
+        HIPCHK(grid_build(s, dQ, m, &gh.g));
+        grid = gh.g.ok;   // non-finite target coordinates: brute force below, like the engine
+    }
+    if (grid) {
+        q_splits = 1;
+        HIPCHK(search_grid(s, dP, n, pc.as<double>(), gh.g, dQ, m, nullptr, keys.as<double>(), idxs.as<uint32_t>()));
+    } else if (f32) {
         if (cb == 8) cb = 16;
         HIPCHK(qrec.alloc(16 * m_pad));
         HIPCHK(qmaxb.alloc(sizeof(unsigned long long)));

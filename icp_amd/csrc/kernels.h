@@ -13,7 +13,7 @@ constexpr int kTileQ   = 1024;   // target points per LDS tile; Q arrays are pad
 constexpr int kCovW    = 12;     // doubles per cov partial: 9 cov sums, sum d^2, 2 spare
 constexpr int kCenW    = 3;      // doubles per centroid partial
 
-enum SearchVariant { kExact = 1, kFma = 2, kF32 = 3 };
+enum SearchVariant { kExact = 1, kFma = 2, kF32 = 3, kGrid = 4 };
 constexpr size_t kPadRows = 2048;  // clouds are padded to this many rows (covers every kernel's tile)
 constexpr size_t kSplitGran = 64;  // target splits are whole multiples of this many targets (>= every cb, even)
 
@@ -51,6 +51,30 @@ hipError_t build_qrec(hipStream_t s, Soa3 Qz, size_t m, size_t m_pad, void *qrec
 hipError_t search_f32(hipStream_t s, int ppl, int cb, Soa3 P, size_t n_pad, const double *pc, Soa3 Qz, const void *qrec,
                       double qmax, size_t m, size_t m_pad, int q_splits, const uint32_t *idx_prev, double *out_key,
                       uint32_t *out_idx);
+
+// Uniform grid over the centred target cloud (grid.hip): same correspondences as the brute-force kernels, found by
+// evaluating only the targets in the cells a query's search box touches.
+struct GridDesc {
+    double lo[3], hi[3];   // bounding box of the targets
+    double inv[3];         // cells per unit length along each axis (0 for an axis of zero extent)
+    int dim[3];            // cells per axis
+    double r0;             // first search radius of an un-seeded query that lies inside the box (half a cell)
+};
+struct Grid {
+    GridDesc d{};
+    size_t cells = 0;
+    uint32_t *start = nullptr;   // cells + 1: first sorted position of each cell, cell id = (cz*dim[1] + cy)*dim[0] + cx
+    uint32_t *perm = nullptr;    // m: original index of each sorted target
+    double *store = nullptr;     // 3 * m: sorted coordinates (SoA)
+    double *sx = nullptr, *sy = nullptr, *sz = nullptr;
+    bool ok = false;             // false: the cloud has non-finite coordinates, use a brute-force variant
+};
+// Builds the grid of Qz[0, m) (allocates; synchronises the stream).  Non-finite coordinates: success with ok = false.
+hipError_t grid_build(hipStream_t s, Soa3 Qz, size_t m, Grid *g);
+void grid_free(Grid *g);
+// out_key / out_idx: one (key, idx) record per source row i < n, laid out like one target split of `search`.
+hipError_t search_grid(hipStream_t s, Soa3 P, size_t n, const double *pc, const Grid &g, Soa3 Qz, size_t m,
+                       const uint32_t *idx_prev, double *out_key, uint32_t *out_idx);
 
 // Merge the splits (lowest index among equal keys), write idx[n], and reduce q (x) p per 1024-row chunk
 // into partial[chunk][12].

@@ -13,6 +13,7 @@
 // followed by an in-index-order sum over chunks, so results do not depend on the grid, on the number of
 // target splits, or on how many GPUs share the source rows.
 #include "kernels.h"
+#include "exact.h"
 
 #include <math.h>
 #include <stdlib.h>
@@ -136,22 +137,6 @@ __global__ __launch_bounds__(kWG) void soa_to_aos_kernel(const double *__restric
 // ------------------------------------------------------------------------------------------------
 // correspondence search
 // ------------------------------------------------------------------------------------------------
-// The oracle's squared distance (reference src/libalg/alg.cpp:22-30 with squared_norm_2/add/add,
-// basic_operations.cpp:5-13): tmp = ((0 + dx*dx) + dy*dy) + dz*dz, r = 0 + tmp; every op rounded.
-__device__ __forceinline__ double d2_exact(double ax, double ay, double az, double qx, double qy, double qz)
-{
-    const double dx = ax - qx, dy = ay - qy, dz = az - qz;
-    return (dx * dx + dy * dy) + dz * dz;
-}
-// Same differences, products fused into the sums: within (1+u)^6 of d2_exact; pre-filter only.
-__device__ __forceinline__ double d2_fused(double ax, double ay, double az, double qx, double qy, double qz)
-{
-    const double dx = ax - qx, dy = ay - qy, dz = az - qz;
-    return __builtin_fma(dz, dz, __builtin_fma(dy, dy, dx * dx));
-}
-// The oracle's comparison key (src/cpu/icp.cpp:83 on top of CPUMatrix.cpp:291-295): sqrt applied twice.
-__device__ __forceinline__ double key_of(double d2) { return sqrt(sqrt(d2)); }
-
 // Slow path, entered by the lanes whose running minimum dropped inside the last block of CB targets:
 // re-evaluates the block un-fused and updates the lexicographic best (key, index) exactly as a scan in target order
 // would.  Invariant on exit: every target not yet scanned that can still beat (bk, bj) has d^2 < bd

@@ -48,6 +48,8 @@ extern "C" {
 #define ICP_AMD_SEARCH_EXACT  1   /* 8 un-fused fp64 ops per pair, the oracle's own sequence                */
 #define ICP_AMD_SEARCH_FMA    2   /* fused fp64 pre-filter + exact re-evaluation of every candidate         */
 #define ICP_AMD_SEARCH_F32    3   /* fp32 pre-filter with a rigorous error bound + the same exact re-evaluation */
+#define ICP_AMD_SEARCH_GRID   4   /* uniform grid over the target: evaluates only the targets near each source point,
+                                     with a rounding-safe stop rule; same indices, O(N) instead of O(N M) per iteration */
 
 typedef struct icp_amd_engine icp_amd_engine;
 

@@ -1,0 +1,131 @@
+"""GPU parity tests of the grid search (icp_amd/csrc/grid.hip): it must return exactly the
+correspondences of the brute-force scan -- the reference's golden indices, the oracle's, and the other variants' --
+on every fixture and on the shapes that stress its stop rule (ties, flat clouds, far-apart clouds, huge and tiny
+scales, non-finite coordinates)."""
+import numpy as np
+import pytest
+
+import icp_amd
+from conftest import ICP_CASES, golden, relerr
+from icp_amd import synth
+from oracle import pyoracle as orc
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-9
+
+
+@pytest.mark.parametrize("name", ICP_CASES)
+def test_grid_stagewise_against_reference(name):
+    g = golden(name)
+    Qz = g["Q"] - g["Qc"]
+    for slot, it in enumerate(g["P_in_iters"]):
+        idx = icp_amd.correspondences(g["P_in"][slot], g["Pc"][it], Qz, search="grid")
+        assert np.array_equal(idx, g["idx"][it]), (name, it, int((idx != g["idx"][it]).sum()))
+
+
+@pytest.mark.parametrize("name", ICP_CASES)
+def test_grid_whole_loop_against_reference(name):
+    """Seeded iterations included: the engine runs every iteration on the grid."""
+    g = golden(name)
+    iters = int(g["iters"])
+    e = icp_amd.Engine(search="grid")
+    e.set_target(g["Q"])
+    e.set_source(g["P"])
+    assert e.search_geometry()["variant"] == "grid"
+    for it in range(iters):
+        e.iterate(1)
+        last = e.get_last()
+        assert np.array_equal(last["idx"], g["idx"][it]), (name, it)
+        assert relerr(last["cov"], g["cov"][it]) < TOL
+    P_out = e.get_source()
+    e.close()
+    assert relerr(P_out, g["P_out"]) < TOL
+
+
+def test_grid_ties_and_lattice():
+    g = golden("ties_corr")
+    idx = icp_amd.correspondences(g["Pz"], np.zeros(3), g["Qz"], search="grid")
+    assert np.array_equal(idx, g["idx"])
+    # integer lattice: masses of exactly equal distances, the lowest index must win whatever the visiting order
+    ax = np.arange(-6, 7, dtype=np.float64)
+    Q = np.stack(np.meshgrid(ax, ax, ax, indexing="ij"), -1).reshape(-1, 3)
+    Q = Q[np.random.RandomState(2).permutation(len(Q))]
+    P = np.concatenate([Q[:500] + 0.5, Q[500:900] + np.array([0.5, 0.0, 0.0]), Q[900:1200]])
+    Qz = Q - orc.mean0(Q)
+    Pc = orc.mean0(P)
+    want = orc.correspondences(P - Pc, Qz)
+    for search in ("grid", "exact"):
+        assert np.array_equal(icp_amd.correspondences(P, Pc, Qz, search=search), want), search
+
+
+def test_grid_edge_shapes_and_placements():
+    rng = np.random.RandomState(3)
+    for n, m in ((1, 1), (1, 5), (7, 1), (63, 65), (1025, 1023), (300, 2049), (2050, 257)):
+        P, Q = rng.randn(n, 3), rng.randn(m, 3)
+        Pc, Qz = orc.mean0(P), Q - orc.mean0(Q)
+        assert np.array_equal(icp_amd.correspondences(P, Pc, Qz, search="grid"), orc.correspondences(P - Pc, Qz)), (n, m)
+    Q = rng.uniform(-1, 1, (4000, 3))
+    Qz = Q - orc.mean0(Q)
+    cases = {
+        "far": rng.uniform(-1, 1, (500, 3)) + np.array([40.0, -25.0, 3.0]),     # every query outside the bounding box
+        "wide": rng.uniform(-30, 30, (500, 3)),                                  # inside and far outside
+        "on_targets": Q[rng.permutation(4000)[:500]],                            # d = 0 for every query
+        "tiny_offsets": Q[:500] + rng.uniform(-1e-14, 1e-14, (500, 3)),
+    }
+    for name, P in cases.items():
+        Pc = np.zeros(3)
+        assert np.array_equal(icp_amd.correspondences(P, Pc, Qz, search="grid"), orc.correspondences(P, Qz)), name
+    # clouds that are flat along one or two axes, or a single repeated point
+    for flat in ((2,), (0, 2), (0, 1, 2)):
+        Qf = Q.copy()
+        Qf[:, list(flat)] = 0.25
+        Qfz = Qf - orc.mean0(Qf)
+        P = rng.uniform(-1.5, 1.5, (700, 3))
+        assert np.array_equal(icp_amd.correspondences(P, np.zeros(3), Qfz, search="grid"), orc.correspondences(P, Qfz)), flat
+
+
+def test_grid_scales_and_nonfinite():
+    P, Q = synth.make_pair(5000, 6000, seed=77)
+    for scale, shift in ((1.0, 0.0), (1e-6, 0.0), (1e6, 0.0), (1.0, 1e4), (1e-3, 50.0), (1e20, 0.0), (1e-20, 0.0), (1e150, 0.0),
+                         (1e-150, 0.0)):
+        Ps, Qs = P * scale + shift, Q * scale + shift
+        outs = []
+        for search in ("exact", "grid"):
+            e = icp_amd.Engine(search=search)
+            e.set_target(Qs)
+            e.set_source(Ps)
+            e.iterate(3)
+            outs.append((e.get_last()["idx"], e.get_source()))
+            e.close()
+        assert np.array_equal(outs[0][0], outs[1][0]), (scale, shift)
+        assert np.array_equal(outs[0][1], outs[1][1], equal_nan=True), (scale, shift)   # 1e150: cov overflows in both
+    # non-finite source rows have no correspondence in either variant; a non-finite target disables the grid
+    Pz, Qz = P - orc.mean0(P), Q - orc.mean0(Q)
+    Pn = Pz.copy()
+    Pn[5, 0], Pn[17, 1], Pn[99, 2] = np.nan, np.inf, -np.inf
+    a = icp_amd.correspondences(Pn, np.zeros(3), Qz, search="exact")
+    b = icp_amd.correspondences(Pn, np.zeros(3), Qz, search="grid")
+    assert np.array_equal(a, b) and a[5] == -1 and a[17] == -1 and a[99] == -1
+    Qn = Qz.copy()
+    Qn[7, 1], Qn[9, 0] = np.inf, np.nan
+    a = icp_amd.correspondences(Pz, np.zeros(3), Qn, search="exact")
+    b = icp_amd.correspondences(Pz, np.zeros(3), Qn, search="grid")
+    assert np.array_equal(a, b)
+
+
+def test_grid_full_sizes_match_brute_force():
+    """BASELINE configs 3 and 4 (100k x 100k, 1M x 1M): three iterations on the grid equal three brute-force ones,
+    bit for bit (indices, covariance, cloud)."""
+    for n in (100000, 1000000):
+        P, Q = synth.make_pair(n, n)
+        outs = {}
+        for search in ("f32", "grid"):
+            e = icp_amd.Engine(search=search)
+            e.set_target(Q)
+            e.set_source(P)
+            e.iterate(3)
+            outs[search] = (e.get_last(), e.get_source())
+            e.close()
+        a, b = outs["f32"], outs["grid"]
+        assert np.array_equal(a[0]["idx"], b[0]["idx"]), n
+        assert np.array_equal(a[0]["cov"], b[0]["cov"]) and np.array_equal(a[1], b[1]), n
