@@ -155,6 +155,11 @@ class Engine:
         check(lib().icp_amd_kernel_ms(self._h, C.byref(avg), C.byref(tot), C.byref(cnt)))
         return avg.value, tot.value, cnt.value
 
+    def grid_stats(self):
+        a, b, c = C.c_uint(), C.c_uint(), C.c_uint()
+        check(lib().icp_amd_grid_stats(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return dict(grid_launches=a.value, brute_force_launches=b.value, last_overflow=c.value)
+
     def search_geometry(self):
         a, b, c, d = C.c_int(), C.c_int(), C.c_int(), C.c_int()
         check(lib().icp_amd_search_geometry(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)))

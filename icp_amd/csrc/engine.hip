@@ -104,6 +104,13 @@ struct icp_amd_engine {
     bool f32_ok = false;        // the fp32 error bound is meaningful for this target's range
     Grid grid;                  // uniform grid over Qz (search variant GRID); built on first use per target
     bool grid_built = false;
+    uint32_t *order = nullptr;  // n_pad: source rows in spatial order (GRID), valid when order_ok
+    bool order_ok = false;
+    GridScratch gscratch;       // queue of the points the grid search hands to its overflow kernel
+    bool use_grid = false;      // planned: search on the grid (variant/ppl/q_splits then describe the brute-force fallback)
+    bool grid_auto = false;     // the grid was chosen by AUTO: fall back to brute force while most points overflow
+    unsigned bf_left = 0, bf_backoff = 0;   // AUTO: brute-force iterations left before the grid is tried again
+    unsigned grid_launches = 0, bf_launches = 0;
 
     // source (local rows)
     size_t n = 0, n_pad = 0, n_global = 0;
@@ -187,6 +194,8 @@ extern "C" int icp_amd_destroy(icp_amd_engine *e)
     free_dev(e->q_store); free_dev(e->qc); free_dev(e->qrec); free_dev(e->qmax2_dev); free_dev(e->p_store); free_dev(e->pc); free_dev(e->stage);
     free_dev(e->keys); free_dev(e->idxs); free_dev(e->idx); free_dev(e->rec);
     grid_free(&e->grid);
+    free_dev(e->order);
+    grid_scratch_free(&e->gscratch);
     if (e->own_part) { free_dev(e->cov_part); free_dev(e->cen_part); }
     if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
@@ -255,18 +264,28 @@ extern "C" int icp_amd_set_target(icp_amd_engine *e, const double *Q, size_t m)
 }
 
 // GRID evaluates only the targets near each source point (grid.hip); the others are brute force over all pairs.
+// Returns 0 for AUTO.
 static int requested_variant(const icp_amd_engine *e)
 {
     int variant = e->opt.search == ICP_AMD_SEARCH_EXACT  ? kExact
                   : e->opt.search == ICP_AMD_SEARCH_FMA  ? kFma
+                  : e->opt.search == ICP_AMD_SEARCH_F32  ? kF32
                   : e->opt.search == ICP_AMD_SEARCH_GRID ? kGrid
-                                                         : kF32;
+                                                         : 0;
     const char *sv = getenv("ICP_AMD_SEARCH");
     if (sv && !strcmp(sv, "fma")) variant = kFma;
     if (sv && !strcmp(sv, "exact")) variant = kExact;
     if (sv && !strcmp(sv, "f32")) variant = kF32;
     if (sv && !strcmp(sv, "grid")) variant = kGrid;
+    if (sv && !strcmp(sv, "auto")) variant = 0;
     return variant;
+}
+// AUTO searches on the grid from this many targets on (below, one brute-force launch is as cheap as it gets).
+static const size_t kAutoGridMinTargets = 2048;
+static bool wants_grid(const icp_amd_engine *e)
+{
+    const int v = requested_variant(e);
+    return v == kGrid || (v == 0 && e->m >= kAutoGridMinTargets);
 }
 
 // Launch geometry of the search kernel: enough workgroups to load every CU several times over, without
@@ -276,8 +295,12 @@ static void choose_geometry(icp_amd_engine *e)
     // Every variant returns identical indices (each candidate is re-evaluated in the oracle's un-fused fp64 sequence);
     // they differ in what the fast path costs per pair: EXACT 9.1 fp64 VALU instructions, FMA 7.1 fp64, F32 3.5 fp32.
     // AUTO = F32, which degrades to FMA when the target's range makes the fp32 bound meaningless.
+    // AUTO = GRID from kAutoGridMinTargets targets on, with F32 as the fallback while the clouds are so far from each
+    // other that most search boxes are huge; F32 itself degrades to FMA when the fp32 bound is meaningless.
     int variant = requested_variant(e);
-    if (variant == kGrid && !(e->grid_built && e->grid.ok)) variant = kF32;   // non-finite target coordinates
+    e->use_grid = wants_grid(e) && e->grid_built && e->grid.ok;   // not ok: non-finite target coordinates
+    e->grid_auto = variant == 0;
+    if (variant == 0 || variant == kGrid) variant = kF32;
     if (variant == kF32 && !e->f32_ok) variant = kFma;
     e->variant = variant;
 
@@ -304,7 +327,6 @@ static void choose_geometry(icp_amd_engine *e)
     splits = (size_t)env_int("ICP_AMD_QSPLITS", (int)splits);
     if (splits < 1) splits = 1;
     if (splits > scan_blocks) splits = scan_blocks;
-    if (variant == kGrid) { ppl = 1; splits = 1; }   // one lane per source point, one (key, idx) record each
     e->ppl = ppl;
     e->q_splits = (int)splits;
     // an un-seeded search re-learns its running minimum in every split: keep the first iteration coarser
@@ -319,7 +341,7 @@ static void choose_geometry(icp_amd_engine *e)
 // Launch geometry + the per-split (key, idx) scratch it needs; re-run whenever the source or the target changes.
 static int plan_search(icp_amd_engine *e)
 {
-    if (requested_variant(e) == kGrid && !e->grid_built) {
+    if (wants_grid(e) && !e->grid_built) {
         HIPCHK(grid_build(e->stream, e->Qz, e->m, &e->grid));
         e->grid_built = true;
     }
@@ -351,8 +373,9 @@ extern "C" int icp_amd_set_source(icp_amd_engine *e, const double *P, size_t n)
     HIPCHK(hipSetDevice(e->opt.device));
     const size_t n_pad = round_up(n ? n : 1, kPadRows);
     if (n_pad != e->n_pad) {
-        free_dev(e->p_store); free_dev(e->idx);
-        e->p_store = nullptr; e->idx = nullptr; e->n_pad = 0;
+        free_dev(e->p_store); free_dev(e->idx); free_dev(e->order);
+        grid_scratch_free(&e->gscratch);
+        e->p_store = nullptr; e->idx = nullptr; e->order = nullptr; e->n_pad = 0;
         HIPCHK(hipMalloc(&e->p_store, 3 * n_pad * sizeof(double)));
         HIPCHK(hipMalloc(&e->idx, n_pad * sizeof(uint32_t)));
         HIPCHK(hipMemset(e->idx, 0xFF, n_pad * sizeof(uint32_t)));
@@ -388,6 +411,16 @@ extern "C" int icp_amd_set_source(icp_amd_engine *e, const double *P, size_t n)
         HIPCHK(hipMemcpyAsync(e->stage, P, n * 3 * sizeof(double), hipMemcpyHostToDevice, e->stream));
     }
     HIPCHK(aos_to_soa(e->stream, e->stage, n, n_pad, nullptr, 0.0, e->P));
+    e->order_ok = false;
+    if (n && wants_grid(e)) {
+        if (!e->gscratch.list) HIPCHK(grid_scratch_alloc(n_pad, &e->gscratch));
+        if (env_int("ICP_AMD_GRID_ORDER", 1)) {
+            if (!e->order) HIPCHK(hipMalloc(&e->order, n_pad * sizeof(uint32_t)));
+            HIPCHK(grid_order(e->stream, e->P, n, e->order));
+            e->order_ok = true;
+        }
+    }
+    e->bf_left = e->bf_backoff = 0;
     HIPCHK(hipStreamSynchronize(e->stream));  // P may be reused by the caller after return
     e->have_source = true;
     e->have_prev = false;
@@ -449,9 +482,23 @@ extern "C" int icp_amd_step_search(icp_amd_engine *e)
             RCCHK(time_begin(e, &a, &b));
         }
         const bool seed = e->have_prev && env_int("ICP_AMD_SEED", 1) != 0;
-        const int splits = seed ? e->q_splits : e->q_splits_first;
-        if (e->variant == kGrid)
-            HIPCHK(search_grid(e->stream, e->P, e->n, e->pc, e->grid, e->Qz, e->m, seed ? e->idx : nullptr, e->keys, e->idxs));
+        bool grid = e->use_grid && e->gscratch.list;
+        if (grid && e->grid_auto) {
+            // The queue length of the most recent grid launch that has finished (a mapped host word, read without
+            // waiting): when most points overflow, the tiled brute-force kernel is the faster exact search.  The grid
+            // is tried again after 1, 2, 4, ... brute-force iterations (the clouds move towards each other).
+            if (e->bf_left == 0 && *e->gscratch.host_mem > e->n / 8) {
+                e->bf_backoff = e->bf_backoff ? (e->bf_backoff < 64 ? 2 * e->bf_backoff : 64) : 1;
+                e->bf_left = e->bf_backoff;
+                *e->gscratch.host_mem = 0;
+            }
+            if (e->bf_left) { --e->bf_left; grid = false; }
+        }
+        const int splits = grid ? 1 : (seed ? e->q_splits : e->q_splits_first);
+        if (grid) ++e->grid_launches; else ++e->bf_launches;
+        if (grid)
+            HIPCHK(search_grid(e->stream, e->P, e->n, e->pc, e->grid, e->Qz, e->m, seed ? e->idx : nullptr,
+                               e->order_ok ? e->order : nullptr, &e->gscratch, e->keys, e->idxs));
         else if (e->variant == kF32)
             HIPCHK(search_f32(e->stream, e->ppl, e->cb, e->P, e->n_pad, e->pc, e->Qz, e->qrec, e->qmax, e->m, e->m_pad, splits,
                               seed ? e->idx : nullptr, e->keys, e->idxs));
@@ -580,7 +627,17 @@ extern "C" int icp_amd_search_geometry(icp_amd_engine *e, int *ppl, int *q_split
     if (ppl) *ppl = e->ppl;
     if (q_splits) *q_splits = e->q_splits;
     if (workgroups) *workgroups = (int)(e->n_pad / ((size_t)kWG * e->ppl)) * e->q_splits;
-    if (variant) *variant = e->variant;
+    if (variant) *variant = e->use_grid ? (int)kGrid : e->variant;
+    return ICP_AMD_OK;
+}
+
+extern "C" int icp_amd_grid_stats(icp_amd_engine *e, unsigned *grid_launches, unsigned *brute_force_launches,
+                                  unsigned *last_overflow)
+{
+    if (!e) return fail(ICP_AMD_EINVAL, "icp_amd_grid_stats: NULL engine");
+    if (grid_launches) *grid_launches = e->grid_launches;
+    if (brute_force_launches) *brute_force_launches = e->bf_launches;
+    if (last_overflow) *last_overflow = e->gscratch.host_mem ? *e->gscratch.host_mem : 0u;
     return ICP_AMD_OK;
 }
 
@@ -942,7 +999,11 @@ extern "C" int icp_amd_correspondences(const double *P, size_t n, const double P
     }
     if (grid) {
         q_splits = 1;
-        HIPCHK(search_grid(s, dP, n, pc.as<double>(), gh.g, dQ, m, nullptr, keys.as<double>(), idxs.as<uint32_t>()));
+        struct ScratchHolder { GridScratch sc; ~ScratchHolder() { grid_scratch_free(&sc); } } sh;
+        HIPCHK(grid_scratch_alloc(n, &sh.sc));
+        HIPCHK(search_grid(s, dP, n, pc.as<double>(), gh.g, dQ, m, nullptr, nullptr, &sh.sc, keys.as<double>(),
+                           idxs.as<uint32_t>()));
+        HIPCHK(hipStreamSynchronize(s));   // the scratch is released on scope exit
     } else if (f32) {
         if (cb == 8) cb = 16;
         HIPCHK(qrec.alloc(16 * m_pad));

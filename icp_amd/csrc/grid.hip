@@ -22,6 +22,7 @@
 #include "exact.h"
 
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 namespace icpk {
@@ -129,12 +130,78 @@ __global__ __launch_bounds__(kWG) void grid_scatter_kernel(const double *__restr
     const size_t j = (size_t)blockIdx.x * kWG + threadIdx.x;
     if (j >= m) return;
     const uint32_t pos = atomicAdd(&cursor[cell[j]], 1u);
-    sx[pos] = qx[j];
-    sy[pos] = qy[j];
-    sz[pos] = qz[j];
+    if (sx) {
+        sx[pos] = qx[j];
+        sy[pos] = qy[j];
+        sz[pos] = qz[j];
+    }
     perm[pos] = (uint32_t)j;
 }
 
+// The cells a box [a - r, a + r]^3 touches, and B = lower bound on the computed d^2 of every target in the other cells.
+struct Box {
+    int cx0, cx1, cy0, cy1, cz0, cz1;
+    double B;
+    bool all;   // the box covers the whole grid
+};
+__device__ __forceinline__ Box make_box(const GridDesc &g, double ax, double ay, double az, double r)
+{
+    Box b;
+    const double xlo = ax - r, xhi = ax + r, ylo = ay - r, yhi = ay + r, zlo = az - r, zhi = az + r;
+    b.cx0 = cell_of(xlo, g.lo[0], g.inv[0], g.dim[0]);
+    b.cx1 = cell_of(xhi, g.lo[0], g.inv[0], g.dim[0]);
+    b.cy0 = cell_of(ylo, g.lo[1], g.inv[1], g.dim[1]);
+    b.cy1 = cell_of(yhi, g.lo[1], g.inv[1], g.dim[1]);
+    b.cz0 = cell_of(zlo, g.lo[2], g.inv[2], g.dim[2]);
+    b.cz1 = cell_of(zhi, g.lo[2], g.inv[2], g.dim[2]);
+    double B = INFINITY;
+    if (b.cx0 > 0) { const double t = ax - xlo; B = __builtin_fmin(B, t * t); }
+    if (b.cx1 < g.dim[0] - 1) { const double t = xhi - ax; B = __builtin_fmin(B, t * t); }
+    if (b.cy0 > 0) { const double t = ay - ylo; B = __builtin_fmin(B, t * t); }
+    if (b.cy1 < g.dim[1] - 1) { const double t = yhi - ay; B = __builtin_fmin(B, t * t); }
+    if (b.cz0 > 0) { const double t = az - zlo; B = __builtin_fmin(B, t * t); }
+    if (b.cz1 < g.dim[2] - 1) { const double t = zhi - az; B = __builtin_fmin(B, t * t); }
+    b.B = B;
+    b.all = b.cx0 == 0 && b.cy0 == 0 && b.cz0 == 0 && b.cx1 == g.dim[0] - 1 && b.cy1 == g.dim[1] - 1 && b.cz1 == g.dim[2] - 1;
+    return b;
+}
+// First radius: the tie band of the seed's distance, or (no seed) up to the targets' bounding box plus half a cell.
+__device__ __forceinline__ double first_radius(const GridDesc &g, double ax, double ay, double az, double amax, double edge)
+{
+    double r;
+    if (edge < INFINITY) {
+        r = sqrt(edge) * (1.0 + 0x1p-10);
+    } else {
+        const double ex = __builtin_fmax(__builtin_fmax(g.lo[0] - ax, ax - g.hi[0]), 0.0);
+        const double ey = __builtin_fmax(__builtin_fmax(g.lo[1] - ay, ay - g.hi[1]), 0.0);
+        const double ez = __builtin_fmax(__builtin_fmax(g.lo[2] - az, az - g.hi[2]), 0.0);
+        r = __builtin_fmax(__builtin_fmax(ex, ey), ez) + g.r0;
+    }
+    return __builtin_fmax(__builtin_fmax(r, 0x1p-30 * amax), 1e-150);   // keep a - r distinguishable from a
+}
+__device__ __forceinline__ double next_radius(double edge, double r)
+{
+    return (edge < INFINITY) ? __builtin_fmax(sqrt(edge) * (1.0 + 0x1p-10), r * 1.0625) : 2.0 * r;
+}
+// One evaluated target: lexicographic (key, index) best among the candidates inside the tie band of the running minimum.
+__device__ __forceinline__ void consider(double d, uint32_t j, double &dmin, double &edge, double &bk, uint32_t &bj)
+{
+    if (d <= edge && d < INFINITY) {
+        const double key = key_of(d);
+        if (key < bk || (key == bk && j < bj)) {
+            bk = key;
+            bj = j;
+        }
+        if (d < dmin) {
+            dmin = d;
+            edge = tie_band(d);
+        }
+    }
+}
+
+// One lane per source point.  A lane whose box is large (more than row_cap rows of cells or eval_cap targets -- an
+// outlier far from every target, or an un-seeded first pass) does not walk it alone while the other 63 lanes of its
+// wave wait: it records what it has found so far and queues the point for search_grid_overflow_kernel.
 __global__ __launch_bounds__(kWG) void search_grid_kernel(const double *__restrict__ px, const double *__restrict__ py,
                                                           const double *__restrict__ pz, const double *__restrict__ pc, size_t n,
                                                           GridDesc g, const uint32_t *__restrict__ start,
@@ -142,11 +209,15 @@ __global__ __launch_bounds__(kWG) void search_grid_kernel(const double *__restri
                                                           const double *__restrict__ sz, const uint32_t *__restrict__ perm,
                                                           const double *__restrict__ qx, const double *__restrict__ qy,
                                                           const double *__restrict__ qz, unsigned m,
-                                                          const uint32_t *__restrict__ idx_prev, double *__restrict__ out_key,
-                                                          uint32_t *__restrict__ out_idx)
+                                                          const uint32_t *__restrict__ idx_prev,
+                                                          const uint32_t *__restrict__ order, int row_cap, unsigned eval_cap,
+                                                          uint32_t *__restrict__ ovf_count, uint32_t *__restrict__ ovf_list,
+                                                          double *__restrict__ out_key, uint32_t *__restrict__ out_idx)
 {
-    const size_t i = (size_t)blockIdx.x * kWG + threadIdx.x;
-    if (i >= n) return;
+    const size_t l = (size_t)blockIdx.x * kWG + threadIdx.x;
+    if (l >= n) return;
+    // order: source rows sorted by position, so that the lanes of a wave walk the same few cells (cache lines shared)
+    const size_t i = order ? order[l] : l;
     const double ax = px[i] - pc[0], ay = py[i] - pc[1], az = pz[i] - pc[2];
     double bk = INFINITY, dmin = INFINITY;   // oracle: min_dist = DBL_MAX on the key, idx = -1
     uint32_t bj = 0xFFFFFFFFu;
@@ -168,57 +239,109 @@ __global__ __launch_bounds__(kWG) void search_grid_kernel(const double *__restri
         }
     }
     double edge = dmin < INFINITY ? tie_band(dmin) : INFINITY;
-    double r;
-    if (edge < INFINITY) {
-        r = sqrt(edge) * (1.0 + 0x1p-10);
-    } else {   // no candidate yet: reach the bounding box of the targets, plus half a cell
-        const double ex = __builtin_fmax(__builtin_fmax(g.lo[0] - ax, ax - g.hi[0]), 0.0);
-        const double ey = __builtin_fmax(__builtin_fmax(g.lo[1] - ay, ay - g.hi[1]), 0.0);
-        const double ez = __builtin_fmax(__builtin_fmax(g.lo[2] - az, az - g.hi[2]), 0.0);
-        r = __builtin_fmax(__builtin_fmax(ex, ey), ez) + g.r0;
-    }
-    r = __builtin_fmax(__builtin_fmax(r, 0x1p-30 * amax), 1e-150);   // keep a - r distinguishable from a
+    double r = first_radius(g, ax, ay, az, amax, edge);
+    unsigned evals = 0;
+    bool defer = false;
     for (;;) {
-        const double xlo = ax - r, xhi = ax + r, ylo = ay - r, yhi = ay + r, zlo = az - r, zhi = az + r;
-        const int cx0 = cell_of(xlo, g.lo[0], g.inv[0], g.dim[0]), cx1 = cell_of(xhi, g.lo[0], g.inv[0], g.dim[0]);
-        const int cy0 = cell_of(ylo, g.lo[1], g.inv[1], g.dim[1]), cy1 = cell_of(yhi, g.lo[1], g.inv[1], g.dim[1]);
-        const int cz0 = cell_of(zlo, g.lo[2], g.inv[2], g.dim[2]), cz1 = cell_of(zhi, g.lo[2], g.inv[2], g.dim[2]);
-        // lower bound on the computed d^2 of every target outside the visited cells
-        double B = INFINITY;
-        if (cx0 > 0) { const double t = ax - xlo; B = __builtin_fmin(B, t * t); }
-        if (cx1 < g.dim[0] - 1) { const double t = xhi - ax; B = __builtin_fmin(B, t * t); }
-        if (cy0 > 0) { const double t = ay - ylo; B = __builtin_fmin(B, t * t); }
-        if (cy1 < g.dim[1] - 1) { const double t = yhi - ay; B = __builtin_fmin(B, t * t); }
-        if (cz0 > 0) { const double t = az - zlo; B = __builtin_fmin(B, t * t); }
-        if (cz1 < g.dim[2] - 1) { const double t = zhi - az; B = __builtin_fmin(B, t * t); }
-        const bool all = cx0 == 0 && cy0 == 0 && cz0 == 0 && cx1 == g.dim[0] - 1 && cy1 == g.dim[1] - 1 && cz1 == g.dim[2] - 1;
-        for (int cz = cz0; cz <= cz1; ++cz) {
-            for (int cy = cy0; cy <= cy1; ++cy) {
+        const Box b = make_box(g, ax, ay, az, r);
+        if (ovf_list && (long)(b.cy1 - b.cy0 + 1) * (long)(b.cz1 - b.cz0 + 1) > (long)row_cap) {
+            defer = true;
+            break;
+        }
+        for (int cz = b.cz0; cz <= b.cz1 && !defer; ++cz) {
+            for (int cy = b.cy0; cy <= b.cy1; ++cy) {
                 // the cells cx0..cx1 of one (cy, cz) row are adjacent in the sorted arrays
                 const size_t row = ((size_t)cz * (size_t)g.dim[1] + (size_t)cy) * (size_t)g.dim[0];
-                const uint32_t k0 = start[row + cx0], k1 = start[row + cx1 + 1];
-                for (uint32_t k = k0; k < k1; ++k) {
-                    const double d = d2_exact(ax, ay, az, sx[k], sy[k], sz[k]);
-                    if (d <= edge && d < INFINITY) {
-                        const double key = key_of(d);
-                        const uint32_t j = perm[k];
-                        if (key < bk || (key == bk && j < bj)) {
-                            bk = key;
-                            bj = j;
-                        }
-                        if (d < dmin) {
-                            dmin = d;
-                            edge = tie_band(d);
-                        }
-                    }
+                const uint32_t k0 = start[row + b.cx0], k1 = start[row + b.cx1 + 1];
+                evals += k1 - k0;
+                if (ovf_list && evals > eval_cap) {
+                    defer = true;
+                    break;
                 }
+                for (uint32_t k = k0; k < k1; ++k)
+                    consider(d2_exact(ax, ay, az, sx[k], sy[k], sz[k]), perm[k], dmin, edge, bk, bj);
             }
         }
-        if (all || B > edge) break;
-        r = (edge < INFINITY) ? __builtin_fmax(sqrt(edge) * (1.0 + 0x1p-10), r * 1.0625) : 2.0 * r;
+        if (defer || b.all || b.B > edge) break;
+        r = next_radius(edge, r);
     }
-    out_key[i] = bk;
+    out_key[i] = bk;   // deferred: the best found so far, the overflow kernel starts from it
     out_idx[i] = bj;
+    if (defer) ovf_list[atomicAdd(ovf_count, 1u)] = (uint32_t)i;
+}
+
+// The queued points, one workgroup each: the 256 lanes walk the box together (waves take rows of cells, lanes stride
+// over a row's targets).  Every lane keeps the lexicographic best of its own candidates inside the tie band of its
+// own running minimum; the target that wins overall is inside every lane's band when its lane meets it, so the
+// lexicographic minimum over the lanes' results is the overall one.
+__global__ __launch_bounds__(kWG) void search_grid_overflow_kernel(
+    const double *__restrict__ px, const double *__restrict__ py, const double *__restrict__ pz, const double *__restrict__ pc,
+    GridDesc g, const uint32_t *__restrict__ start, const double *__restrict__ sx, const double *__restrict__ sy,
+    const double *__restrict__ sz, const uint32_t *__restrict__ perm, const double *__restrict__ qx,
+    const double *__restrict__ qy, const double *__restrict__ qz, unsigned m, const uint32_t *__restrict__ ovf_count,
+    uint32_t *__restrict__ ovf_count_next, const uint32_t *__restrict__ ovf_list, uint32_t *__restrict__ host_count,
+    double *__restrict__ out_key, uint32_t *__restrict__ out_idx)
+{
+    __shared__ double s_d[kWG / 64], s_k[kWG / 64];
+    __shared__ uint32_t s_j[kWG / 64];
+    const unsigned count = *ovf_count;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        *ovf_count_next = 0;                  // the counter the next launch of search_grid_kernel appends to
+        if (host_count) *host_count = count;  // a hint for the host's choice of variant, read without synchronisation
+    }
+    const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (unsigned q = blockIdx.x; q < count; q += gridDim.x) {
+        const size_t i = ovf_list[q];
+        const double ax = px[i] - pc[0], ay = py[i] - pc[1], az = pz[i] - pc[2];
+        const double amax = __builtin_fmax(__builtin_fmax(__builtin_fabs(ax), __builtin_fabs(ay)), __builtin_fabs(az));
+        double bk = INFINITY, dmin = INFINITY;
+        uint32_t bj = 0xFFFFFFFFu;
+        const uint32_t js = out_idx[i];
+        if (js < m) {
+            const double d = d2_exact(ax, ay, az, qx[js], qy[js], qz[js]);
+            if (d < INFINITY) {
+                dmin = d;
+                bk = key_of(d);
+                bj = js;
+            }
+        }
+        double edge = dmin < INFINITY ? tie_band(dmin) : INFINITY;
+        double r = first_radius(g, ax, ay, az, amax, edge);
+        for (;;) {   // every quantity that steers this loop is uniform over the workgroup
+            const Box b = make_box(g, ax, ay, az, r);
+            const long ny = b.cy1 - b.cy0 + 1, rows = ny * (long)(b.cz1 - b.cz0 + 1);
+            for (long rr = wave; rr < rows; rr += kWG / 64) {
+                const int cz = b.cz0 + (int)(rr / ny), cy = b.cy0 + (int)(rr % ny);
+                const size_t row = ((size_t)cz * (size_t)g.dim[1] + (size_t)cy) * (size_t)g.dim[0];
+                const uint32_t k0 = start[row + b.cx0], k1 = start[row + b.cx1 + 1];
+                for (uint32_t k = k0 + lane; k < k1; k += 64)
+                    consider(d2_exact(ax, ay, az, sx[k], sy[k], sz[k]), perm[k], dmin, edge, bk, bj);
+            }
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) {
+                const double d2 = __shfl_xor(dmin, o, 64), k2 = __shfl_xor(bk, o, 64);
+                const uint32_t j2 = __shfl_xor(bj, o, 64);
+                dmin = __builtin_fmin(dmin, d2);
+                if (k2 < bk || (k2 == bk && j2 < bj)) { bk = k2; bj = j2; }
+            }
+            __syncthreads();   // the previous pass's reads of s_* are done
+            if (lane == 0) { s_d[wave] = dmin; s_k[wave] = bk; s_j[wave] = bj; }
+            __syncthreads();
+            dmin = s_d[0]; bk = s_k[0]; bj = s_j[0];
+#pragma unroll
+            for (int w = 1; w < kWG / 64; ++w) {
+                dmin = __builtin_fmin(dmin, s_d[w]);
+                if (s_k[w] < bk || (s_k[w] == bk && s_j[w] < bj)) { bk = s_k[w]; bj = s_j[w]; }
+            }
+            edge = dmin < INFINITY ? tie_band(dmin) : INFINITY;
+            if (b.all || b.B > edge) break;
+            r = next_radius(edge, r);
+        }
+        if (threadIdx.x == 0) {
+            out_key[i] = bk;
+            out_idx[i] = bj;
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -233,9 +356,9 @@ void grid_free(Grid *g)
     *g = Grid{};
 }
 
-// Cell size: about four targets per cell of the occupied volume (area / length when the cloud is flat along some
+// Cell size: about per_cell points per cell of the occupied volume (area / length when the cloud is flat along some
 // axes), at most 1024 cells per axis and 2^22 cells in all.
-static void choose_cells(const double lo[3], const double hi[3], size_t m, GridDesc *d)
+static void choose_cells(const double lo[3], const double hi[3], size_t m, double per_cell, GridDesc *d)
 {
     double ext[3];
     int active = 0;
@@ -244,7 +367,7 @@ static void choose_cells(const double lo[3], const double hi[3], size_t m, GridD
         ext[k] = hi[k] - lo[k];
         if (ext[k] > 0.0) { ++active; vol *= ext[k]; }
     }
-    double want = (double)m / 4.0;
+    double want = (double)m / per_cell;
     if (want < 1.0) want = 1.0;
     if (want > 4194304.0) want = 4194304.0;
     double h = active ? pow(vol / want, 1.0 / active) : 1.0;
@@ -277,7 +400,8 @@ static void choose_cells(const double lo[3], const double hi[3], size_t m, GridD
     d->r0 = hmin < INFINITY ? 0.5 * hmin : 1.0;
 }
 
-hipError_t grid_build(hipStream_t s, Soa3 Qz, size_t m, Grid *g)
+// Files the points into cells: g->start, g->perm and (with_coords) the sorted coordinates.
+static hipError_t grid_sort(hipStream_t s, Soa3 Qz, size_t m, double per_cell, bool with_coords, Grid *g)
 {
     grid_free(g);
     if (m == 0 || m > 0xFFFFFFF0u) return hipErrorInvalidValue;
@@ -305,20 +429,22 @@ hipError_t grid_build(hipStream_t s, Soa3 Qz, size_t m, Grid *g)
             hi[k] = from_ordered_bits(host_bb[3 + k]);
             finite = finite && isfinite(lo[k]) && isfinite(hi[k]) && isfinite(hi[k] - lo[k]);
         }
-        if (!finite) {   // NaN / inf coordinates: no grid; the caller uses a brute-force variant
+        if (!finite) {   // NaN / inf coordinates: no grid
             g->ok = false;
             e = hipSuccess;
             goto done;
         }
-        choose_cells(lo, hi, m, &g->d);
+        choose_cells(lo, hi, m, per_cell, &g->d);
     }
     g->cells = (size_t)g->d.dim[0] * (size_t)g->d.dim[1] * (size_t)g->d.dim[2];
     GRID_TRY(hipMalloc(&g->start, (g->cells + 1) * sizeof(uint32_t)));
     GRID_TRY(hipMalloc(&g->perm, m * sizeof(uint32_t)));
-    GRID_TRY(hipMalloc(&g->store, 3 * m * sizeof(double)));
-    g->sx = g->store;
-    g->sy = g->store + m;
-    g->sz = g->store + 2 * m;
+    if (with_coords) {
+        GRID_TRY(hipMalloc(&g->store, 3 * m * sizeof(double)));
+        g->sx = g->store;
+        g->sy = g->store + m;
+        g->sz = g->store + 2 * m;
+    }
     GRID_TRY(hipMalloc(&cell, m * sizeof(uint32_t)));
     GRID_TRY(hipMalloc(&counts, g->cells * sizeof(uint32_t)));
     GRID_TRY(hipMalloc(&cursor, g->cells * sizeof(uint32_t)));
@@ -342,14 +468,88 @@ done:
     return e;
 }
 
+static double env_per_cell(const char *name, double dflt)
+{
+    const char *v = getenv(name);
+    const double x = v ? atof(v) : 0.0;
+    return x >= 0.25 && x <= 65536.0 ? x : dflt;
+}
+
+hipError_t grid_build(hipStream_t s, Soa3 Qz, size_t m, Grid *g)
+{
+    return grid_sort(s, Qz, m, env_per_cell("ICP_AMD_GRID_PER_CELL", 4.0), true, g);
+}
+
+__global__ __launch_bounds__(kWG) void iota_kernel(uint32_t *out, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * kWG + threadIdx.x;
+    if (i < n) out[i] = (uint32_t)i;
+}
+
+// order[0, n) = the source rows sorted by the cell of a coarse grid over the source cloud itself (about two waves of
+// points per cell, cells in x-fastest order).  Rigid motions keep neighbours together, so the order computed once
+// stays good for every iteration.  Rows with non-finite coordinates anywhere: identity order.
+hipError_t grid_order(hipStream_t s, Soa3 P, size_t n, uint32_t *order)
+{
+    if (n == 0) return hipSuccess;
+    Grid g;
+    hipError_t e = grid_sort(s, P, n, 128.0, false, &g);
+    if (e != hipSuccess) return e;
+    if (g.ok) {
+        e = hipMemcpyAsync(order, g.perm, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, s);
+    } else {
+        iota_kernel<<<(unsigned)((n + kWG - 1) / kWG), kWG, 0, s>>>(order, n);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    grid_free(&g);
+    return e;
+}
+
 hipError_t search_grid(hipStream_t s, Soa3 P, size_t n, const double *pc, const Grid &g, Soa3 Qz, size_t m,
-                       const uint32_t *idx_prev, double *out_key, uint32_t *out_idx)
+                       const uint32_t *idx_prev, const uint32_t *order, GridScratch *sc, double *out_key, uint32_t *out_idx)
 {
     if (!g.ok || m == 0 || m > 0xFFFFFFF0u) return hipErrorInvalidValue;
     if (n == 0) return hipSuccess;
+    const int row_cap = getenv("ICP_AMD_GRID_ROWCAP") ? atoi(getenv("ICP_AMD_GRID_ROWCAP")) : 64;
+    const int eval_cap = getenv("ICP_AMD_GRID_EVALCAP") ? atoi(getenv("ICP_AMD_GRID_EVALCAP")) : 768;
+    uint32_t *cnt = sc ? sc->count2 + sc->parity : nullptr, *cnt_next = sc ? sc->count2 + (sc->parity ^ 1) : nullptr;
     search_grid_kernel<<<(unsigned)((n + kWG - 1) / kWG), kWG, 0, s>>>(P.x, P.y, P.z, pc, n, g.d, g.start, g.sx, g.sy, g.sz, g.perm,
-                                                                      Qz.x, Qz.y, Qz.z, (unsigned)m, idx_prev, out_key, out_idx);
+                                                                      Qz.x, Qz.y, Qz.z, (unsigned)m, idx_prev, order, row_cap,
+                                                                      (unsigned)eval_cap, cnt, sc ? sc->list : nullptr, out_key,
+                                                                      out_idx);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess || !sc) return e;
+    size_t wgs = n < 2048 ? n : 2048;
+    search_grid_overflow_kernel<<<(unsigned)wgs, kWG, 0, s>>>(P.x, P.y, P.z, pc, g.d, g.start, g.sx, g.sy, g.sz, g.perm, Qz.x, Qz.y,
+                                                             Qz.z, (unsigned)m, cnt, cnt_next, sc->list, sc->host_count, out_key,
+                                                             out_idx);
+    sc->parity ^= 1;
     return hipGetLastError();
+}
+
+hipError_t grid_scratch_alloc(size_t n, GridScratch *sc)
+{
+    grid_scratch_free(sc);
+    hipError_t e = hipMalloc(&sc->count2, 2 * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMemset(sc->count2, 0, 2 * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc(&sc->list, (n ? n : 1) * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipHostMalloc((void **)&sc->host_mem, sizeof(uint32_t), hipHostMallocMapped);
+    if (e == hipSuccess) {
+        *sc->host_mem = 0;
+        e = hipHostGetDevicePointer((void **)&sc->host_count, (void *)sc->host_mem, 0);
+    }
+    if (e != hipSuccess) grid_scratch_free(sc);
+    return e;
+}
+
+void grid_scratch_free(GridScratch *sc)
+{
+    if (!sc) return;
+    if (sc->count2) (void)hipFree(sc->count2);
+    if (sc->list) (void)hipFree(sc->list);
+    if (sc->host_mem) (void)hipHostFree((void *)sc->host_mem);
+    *sc = GridScratch{};
 }
 
 }  // namespace icpk

@@ -73,8 +73,23 @@ struct Grid {
 hipError_t grid_build(hipStream_t s, Soa3 Qz, size_t m, Grid *g);
 void grid_free(Grid *g);
 // out_key / out_idx: one (key, idx) record per source row i < n, laid out like one target split of `search`.
+// Queue of the source points whose search box is too large for one lane (they are finished by a second kernel, one
+// workgroup each).  count2: two counters used alternately (each launch zeroes the other one); host_mem: the last
+// launch's queue length, written by the device into mapped host memory (a hint, read without synchronisation).
+struct GridScratch {
+    uint32_t *count2 = nullptr;
+    uint32_t *list = nullptr;               // n entries
+    volatile uint32_t *host_mem = nullptr;  // host address
+    uint32_t *host_count = nullptr;         // device address of the same word
+    int parity = 0;
+};
+hipError_t grid_scratch_alloc(size_t n, GridScratch *sc);
+void grid_scratch_free(GridScratch *sc);
+// order: optional processing order of the source rows (grid_order), a permutation of [0, n); results do not depend on it.
+// sc == nullptr: every lane finishes its own point, however large its box.
 hipError_t search_grid(hipStream_t s, Soa3 P, size_t n, const double *pc, const Grid &g, Soa3 Qz, size_t m,
-                       const uint32_t *idx_prev, double *out_key, uint32_t *out_idx);
+                       const uint32_t *idx_prev, const uint32_t *order, GridScratch *sc, double *out_key, uint32_t *out_idx);
+hipError_t grid_order(hipStream_t s, Soa3 P, size_t n, uint32_t *order);
 
 // Merge the splits (lowest index among equal keys), write idx[n], and reduce q (x) p per 1024-row chunk
 // into partial[chunk][12].

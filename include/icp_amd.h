@@ -44,7 +44,8 @@ extern "C" {
 #define ICP_AMD_METHOD_BATCH       3
 
 /* Correspondence-search kernel variants (engine option `search`); every variant returns identical indices. */
-#define ICP_AMD_SEARCH_AUTO   0   /* = F32 when the clouds' range allows it, else FMA                        */
+#define ICP_AMD_SEARCH_AUTO   0   /* GRID from 2048 targets on (F32 while most search boxes are huge), else F32;
+                                     F32 itself degrades to FMA when the clouds' range defeats the fp32 bound  */
 #define ICP_AMD_SEARCH_EXACT  1   /* 8 un-fused fp64 ops per pair, the oracle's own sequence                */
 #define ICP_AMD_SEARCH_FMA    2   /* fused fp64 pre-filter + exact re-evaluation of every candidate         */
 #define ICP_AMD_SEARCH_F32    3   /* fp32 pre-filter with a rigorous error bound + the same exact re-evaluation */
@@ -130,6 +131,9 @@ int icp_amd_get_target_centroid(icp_amd_engine *e, double Qc[3]);
 int icp_amd_kernel_ms(icp_amd_engine *e, double *search_avg_ms, double *search_total_ms, unsigned *launches);
 /* Launch geometry chosen for the search kernel (for reports). */
 int icp_amd_search_geometry(icp_amd_engine *e, int *points_per_lane, int *q_splits, int *workgroups, int *variant);
+/* Search launches so far by kind, and the number of source points the most recent finished grid launch handed to its
+ * overflow kernel (for reports; does not synchronise). */
+int icp_amd_grid_stats(icp_amd_engine *e, unsigned *grid_launches, unsigned *brute_force_launches, unsigned *last_overflow);
 
 /* ---- multi-registration mode (BASELINE config 5: thousands of small independent registrations).
  *      No counterpart in the reference: its `-batch` flag strip-mines ONE registration 16 source rows at a time

@@ -129,3 +129,61 @@ def test_grid_full_sizes_match_brute_force():
         a, b = outs["f32"], outs["grid"]
         assert np.array_equal(a[0]["idx"], b[0]["idx"]), n
         assert np.array_equal(a[0]["cov"], b[0]["cov"]) and np.array_equal(a[1], b[1]), n
+
+
+def test_grid_overflow_queue_and_auto_fallback(monkeypatch):
+    """Points whose box is too large for one lane are finished by the overflow kernel (one workgroup each); with tiny
+    caps every point takes that route.  Partial overlap / outliers exercise it with the default caps.  AUTO falls back
+    to brute force while most points overflow.  Results never change."""
+    rng = np.random.RandomState(11)
+    P, Q = synth.make_pair(6000, 7000, seed=5)
+    Pc, Qz = orc.mean0(P), Q - orc.mean0(Q)
+    want = orc.correspondences(P - Pc, Qz, nthreads=4)
+    for rowcap, evalcap in ((1, 8), (64, 1), (2, 100000)):
+        monkeypatch.setenv("ICP_AMD_GRID_ROWCAP", str(rowcap))
+        monkeypatch.setenv("ICP_AMD_GRID_EVALCAP", str(evalcap))
+        assert np.array_equal(icp_amd.correspondences(P, Pc, Qz, search="grid"), want), (rowcap, evalcap)
+        e = icp_amd.Engine(search="grid")
+        e.set_target(Q)
+        e.set_source(P)
+        e.iterate(3)
+        got = e.get_last()["idx"]
+        e.close()
+        ref = orc.icp(P, Q, 3, trace=True, nthreads=4)
+        assert np.array_equal(got, ref["idx"][-1]), (rowcap, evalcap)
+    monkeypatch.delenv("ICP_AMD_GRID_ROWCAP")
+    monkeypatch.delenv("ICP_AMD_GRID_EVALCAP")
+    # outliers: a tenth of the source points far away from every target, and a source that overlaps half the target
+    Po = P.copy()
+    Po[::10] += rng.uniform(3, 6, (600, 3))
+    Ph = P[P[:, 0] > np.median(P[:, 0])]
+    for name, Px in (("outliers", Po), ("half", Ph)):
+        outs = []
+        for search in ("exact", "grid", "auto"):
+            e = icp_amd.Engine(search=search)
+            e.set_target(Q)
+            e.set_source(Px)
+            e.iterate(4)
+            outs.append((e.get_last()["idx"], e.get_source()))
+            e.close()
+        for o in outs[1:]:
+            assert np.array_equal(outs[0][0], o[0]) and np.array_equal(outs[0][1], o[1]), name
+    # clouds at right angles (a long thin target, the source turned by 90 degrees): most boxes are huge, AUTO must
+    # still return the brute-force result while it switches between the grid and the tiled kernel
+    Ql = rng.uniform(-1, 1, (20000, 3)) * np.array([20.0, 1.0, 1.0])
+    Pl = Ql[rng.permutation(20000)][:, [1, 0, 2]] + 0.01 * rng.randn(20000, 3)
+    outs, stats = [], {}
+    for search in ("f32", "auto", "grid"):
+        e = icp_amd.Engine(search=search)
+        e.set_target(Ql)
+        e.set_source(Pl)
+        for _ in range(6):
+            e.iterate(1)
+            e.sync()
+        outs.append((e.get_last()["idx"], e.get_source()))
+        stats[search] = e.grid_stats()
+        e.close()
+    for o in outs[1:]:
+        assert np.array_equal(outs[0][0], o[0]) and np.array_equal(outs[0][1], o[1])
+    assert stats["f32"]["grid_launches"] == 0 and stats["grid"]["brute_force_launches"] == 0
+    assert stats["auto"]["grid_launches"] >= 1 and stats["auto"]["brute_force_launches"] >= 1, stats

@@ -123,6 +123,8 @@ def test_bench_two_ranks_on_one_gpu_over_gloo():
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["parallelism"] == "p-shard2"
+    assert d["config"]["search"]["variant"] == "f32" and d["grid_search"]["search"]["variant"] == "grid"
+    assert d["grid_search"]["iters_per_sec"] > 0
     # same workload on one rank: the registration must reach the same rms (bit-identical results whatever the sharding)
     r1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--src", "60000", "--tgt", "50000",
                          "--no-cpu-baseline", "--no-fp64-variants"], env=env, capture_output=True, text=True, timeout=280)
