@@ -96,6 +96,7 @@ struct icp_amd_engine {
     // target
     size_t m = 0, m_pad = 0;
     double *q_store = nullptr;  // 3 * m_pad
+    double4 *q_rec = nullptr;   // m_pad row-major {x,y,z,0} copy of Qz for gathers by index
     Soa3 Qz{nullptr, nullptr, nullptr};
     double *qc = nullptr;       // 3
     void *qrec = nullptr;       // m_pad 16-byte fp32 records for the f32 pre-filter
@@ -191,7 +192,7 @@ extern "C" int icp_amd_destroy(icp_amd_engine *e)
     (void)hipSetDevice(e->opt.device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     for (hipEvent_t ev : e->ev) (void)hipEventDestroy(ev);
-    free_dev(e->q_store); free_dev(e->qc); free_dev(e->qrec); free_dev(e->qmax2_dev); free_dev(e->p_store); free_dev(e->pc); free_dev(e->stage);
+    free_dev(e->q_store); free_dev(e->q_rec); free_dev(e->qc); free_dev(e->qrec); free_dev(e->qmax2_dev); free_dev(e->p_store); free_dev(e->pc); free_dev(e->stage);
     free_dev(e->keys); free_dev(e->idxs); free_dev(e->idx); free_dev(e->rec);
     grid_free(&e->grid);
     free_dev(e->order);
@@ -225,14 +226,15 @@ extern "C" int icp_amd_set_target(icp_amd_engine *e, const double *Q, size_t m)
     HIPCHK(hipSetDevice(e->opt.device));
     const size_t m_pad = round_up(m, kPadRows);
     if (m_pad != e->m_pad) {
-        free_dev(e->q_store); free_dev(e->qrec);
-        e->q_store = nullptr; e->qrec = nullptr;
+        free_dev(e->q_store); free_dev(e->qrec); free_dev(e->q_rec);
+        e->q_store = nullptr; e->qrec = nullptr; e->q_rec = nullptr;
         e->m_pad = 0;
         HIPCHK(hipMalloc(&e->q_store, 3 * m_pad * sizeof(double)));
+        HIPCHK(hipMalloc(&e->q_rec, m_pad * sizeof(double4)));
         HIPCHK(hipMalloc(&e->qrec, 16 * m_pad));
         if (!e->qmax2_dev) HIPCHK(hipMalloc(&e->qmax2_dev, sizeof(unsigned long long)));
         e->m_pad = m_pad;
-        e->Qz = Soa3{e->q_store, e->q_store + m_pad, e->q_store + 2 * m_pad};
+        e->Qz = Soa3{e->q_store, e->q_store + m_pad, e->q_store + 2 * m_pad, e->q_rec};
     }
     e->m = m;
     RCCHK(ensure_stage(e, m));
@@ -245,6 +247,7 @@ extern "C" int icp_amd_set_target(icp_amd_engine *e, const double *Q, size_t m)
     if (er == hipSuccess) er = finalize_centroid(e->stream, part, chunks, (double)m, e->qc);
     if (er == hipSuccess)
         er = aos_to_soa(e->stream, e->stage, m, m_pad, e->qc, std::numeric_limits<double>::infinity(), e->Qz);
+    if (er == hipSuccess) er = build_rec(e->stream, e->Qz, m_pad);
     if (er == hipSuccess) er = build_qrec(e->stream, e->Qz, m, m_pad, e->qrec, e->qmax2_dev);
     unsigned long long bits = 0;
     if (er == hipSuccess) er = hipMemcpyAsync(&bits, e->qmax2_dev, sizeof bits, hipMemcpyDeviceToHost, e->stream);

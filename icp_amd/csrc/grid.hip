@@ -119,22 +119,17 @@ __global__ __launch_bounds__(1024) void grid_scan_kernel(const uint32_t *__restr
     if (threadIdx.x == 1023) start[cells] = part[1023];
 }
 
-// targets sorted by cell: coordinates (SoA) and original index.  The order inside a cell is arbitrary (atomic
+// targets sorted by cell: one 32-byte record {x, y, z, original index} each (one load per candidate), plus the index alone.  The order inside a cell is arbitrary (atomic
 // cursor); the search does not depend on it.
 __global__ __launch_bounds__(kWG) void grid_scatter_kernel(const double *__restrict__ qx, const double *__restrict__ qy,
                                                            const double *__restrict__ qz, size_t m,
                                                            const uint32_t *__restrict__ cell, uint32_t *__restrict__ cursor,
-                                                           double *__restrict__ sx, double *__restrict__ sy,
-                                                           double *__restrict__ sz, uint32_t *__restrict__ perm)
+                                                           double4 *__restrict__ rec, uint32_t *__restrict__ perm)
 {
     const size_t j = (size_t)blockIdx.x * kWG + threadIdx.x;
     if (j >= m) return;
     const uint32_t pos = atomicAdd(&cursor[cell[j]], 1u);
-    if (sx) {
-        sx[pos] = qx[j];
-        sy[pos] = qy[j];
-        sz[pos] = qz[j];
-    }
+    if (rec) rec[pos] = make_double4(qx[j], qy[j], qz[j], __longlong_as_double((long long)j));   // index as a bit pattern
     perm[pos] = (uint32_t)j;
 }
 
@@ -199,16 +194,32 @@ __device__ __forceinline__ void consider(double d, uint32_t j, double &dmin, dou
     }
 }
 
+__device__ __forceinline__ double seed_d2(double ax, double ay, double az, uint32_t js, const double *__restrict__ qx,
+                                          const double *__restrict__ qy, const double *__restrict__ qz,
+                                          const double4 *__restrict__ qrec4)
+{
+    if (qrec4) {
+        const double4 v = qrec4[js];
+        return d2_exact(ax, ay, az, v.x, v.y, v.z);
+    }
+    return d2_exact(ax, ay, az, qx[js], qy[js], qz[js]);
+}
+__device__ __forceinline__ void consider_rec(double ax, double ay, double az, const double4 v, double &dmin, double &edge,
+                                             double &bk, uint32_t &bj)
+{
+    consider(d2_exact(ax, ay, az, v.x, v.y, v.z), (uint32_t)__double_as_longlong(v.w), dmin, edge, bk, bj);
+}
+
 // One lane per source point.  A lane whose box is large (more than row_cap rows of cells or eval_cap targets -- an
 // outlier far from every target, or an un-seeded first pass) does not walk it alone while the other 63 lanes of its
 // wave wait: it records what it has found so far and queues the point for search_grid_overflow_kernel.
 __global__ __launch_bounds__(kWG) void search_grid_kernel(const double *__restrict__ px, const double *__restrict__ py,
                                                           const double *__restrict__ pz, const double *__restrict__ pc, size_t n,
                                                           GridDesc g, const uint32_t *__restrict__ start,
-                                                          const double *__restrict__ sx, const double *__restrict__ sy,
-                                                          const double *__restrict__ sz, const uint32_t *__restrict__ perm,
+                                                          const double4 *__restrict__ rec,
                                                           const double *__restrict__ qx, const double *__restrict__ qy,
-                                                          const double *__restrict__ qz, unsigned m,
+                                                          const double *__restrict__ qz, const double4 *__restrict__ qrec4,
+                                                          unsigned m,
                                                           const uint32_t *__restrict__ idx_prev,
                                                           const uint32_t *__restrict__ order, int row_cap, unsigned eval_cap,
                                                           uint32_t *__restrict__ ovf_count, uint32_t *__restrict__ ovf_list,
@@ -230,7 +241,7 @@ __global__ __launch_bounds__(kWG) void search_grid_kernel(const double *__restri
     if (idx_prev) {
         const uint32_t js = idx_prev[i];
         if (js < m) {
-            const double d = d2_exact(ax, ay, az, qx[js], qy[js], qz[js]);
+            const double d = seed_d2(ax, ay, az, js, qx, qy, qz, qrec4);
             if (d < INFINITY) {
                 dmin = d;
                 bk = key_of(d);
@@ -258,8 +269,7 @@ __global__ __launch_bounds__(kWG) void search_grid_kernel(const double *__restri
                     defer = true;
                     break;
                 }
-                for (uint32_t k = k0; k < k1; ++k)
-                    consider(d2_exact(ax, ay, az, sx[k], sy[k], sz[k]), perm[k], dmin, edge, bk, bj);
+                for (uint32_t k = k0; k < k1; ++k) consider_rec(ax, ay, az, rec[k], dmin, edge, bk, bj);
             }
         }
         if (defer || b.all || b.B > edge) break;
@@ -276,9 +286,9 @@ __global__ __launch_bounds__(kWG) void search_grid_kernel(const double *__restri
 // lexicographic minimum over the lanes' results is the overall one.
 __global__ __launch_bounds__(kWG) void search_grid_overflow_kernel(
     const double *__restrict__ px, const double *__restrict__ py, const double *__restrict__ pz, const double *__restrict__ pc,
-    GridDesc g, const uint32_t *__restrict__ start, const double *__restrict__ sx, const double *__restrict__ sy,
-    const double *__restrict__ sz, const uint32_t *__restrict__ perm, const double *__restrict__ qx,
-    const double *__restrict__ qy, const double *__restrict__ qz, unsigned m, const uint32_t *__restrict__ ovf_count,
+    GridDesc g, const uint32_t *__restrict__ start, const double4 *__restrict__ rec, const double *__restrict__ qx,
+    const double *__restrict__ qy, const double *__restrict__ qz, const double4 *__restrict__ qrec4, unsigned m,
+    const uint32_t *__restrict__ ovf_count,
     uint32_t *__restrict__ ovf_count_next, const uint32_t *__restrict__ ovf_list, uint32_t *__restrict__ host_count,
     double *__restrict__ out_key, uint32_t *__restrict__ out_idx)
 {
@@ -298,7 +308,7 @@ __global__ __launch_bounds__(kWG) void search_grid_overflow_kernel(
         uint32_t bj = 0xFFFFFFFFu;
         const uint32_t js = out_idx[i];
         if (js < m) {
-            const double d = d2_exact(ax, ay, az, qx[js], qy[js], qz[js]);
+            const double d = seed_d2(ax, ay, az, js, qx, qy, qz, qrec4);
             if (d < INFINITY) {
                 dmin = d;
                 bk = key_of(d);
@@ -314,8 +324,7 @@ __global__ __launch_bounds__(kWG) void search_grid_overflow_kernel(
                 const int cz = b.cz0 + (int)(rr / ny), cy = b.cy0 + (int)(rr % ny);
                 const size_t row = ((size_t)cz * (size_t)g.dim[1] + (size_t)cy) * (size_t)g.dim[0];
                 const uint32_t k0 = start[row + b.cx0], k1 = start[row + b.cx1 + 1];
-                for (uint32_t k = k0 + lane; k < k1; k += 64)
-                    consider(d2_exact(ax, ay, az, sx[k], sy[k], sz[k]), perm[k], dmin, edge, bk, bj);
+                for (uint32_t k = k0 + lane; k < k1; k += 64) consider_rec(ax, ay, az, rec[k], dmin, edge, bk, bj);
             }
 #pragma unroll
             for (int o = 32; o >= 1; o >>= 1) {
@@ -352,7 +361,7 @@ void grid_free(Grid *g)
     if (!g) return;
     if (g->start) (void)hipFree(g->start);
     if (g->perm) (void)hipFree(g->perm);
-    if (g->store) (void)hipFree(g->store);
+    if (g->rec) (void)hipFree(g->rec);
     *g = Grid{};
 }
 
@@ -415,7 +424,7 @@ static hipError_t grid_sort(hipStream_t s, Soa3 Qz, size_t m, double per_cell, b
     GRID_TRY(hipMemsetAsync(bb + 3, 0x00, 3 * sizeof(unsigned long long), s));
     {
         size_t blocks = (m + kWG - 1) / kWG;
-        if (blocks > 2048) blocks = 2048;
+        if (blocks > 256) blocks = 256;   // every wave ends in six atomics on the same six words
         grid_bbox_kernel<<<(unsigned)blocks, kWG, 0, s>>>(Qz.x, Qz.y, Qz.z, m, bb);
     }
     GRID_TRY(hipGetLastError());
@@ -439,12 +448,7 @@ static hipError_t grid_sort(hipStream_t s, Soa3 Qz, size_t m, double per_cell, b
     g->cells = (size_t)g->d.dim[0] * (size_t)g->d.dim[1] * (size_t)g->d.dim[2];
     GRID_TRY(hipMalloc(&g->start, (g->cells + 1) * sizeof(uint32_t)));
     GRID_TRY(hipMalloc(&g->perm, m * sizeof(uint32_t)));
-    if (with_coords) {
-        GRID_TRY(hipMalloc(&g->store, 3 * m * sizeof(double)));
-        g->sx = g->store;
-        g->sy = g->store + m;
-        g->sz = g->store + 2 * m;
-    }
+    if (with_coords) GRID_TRY(hipMalloc(&g->rec, m * sizeof(double4)));
     GRID_TRY(hipMalloc(&cell, m * sizeof(uint32_t)));
     GRID_TRY(hipMalloc(&counts, g->cells * sizeof(uint32_t)));
     GRID_TRY(hipMalloc(&cursor, g->cells * sizeof(uint32_t)));
@@ -453,8 +457,7 @@ static hipError_t grid_sort(hipStream_t s, Soa3 Qz, size_t m, double per_cell, b
     GRID_TRY(hipGetLastError());
     grid_scan_kernel<<<1, 1024, 0, s>>>(counts, g->cells, g->start, cursor);
     GRID_TRY(hipGetLastError());
-    grid_scatter_kernel<<<(unsigned)((m + kWG - 1) / kWG), kWG, 0, s>>>(Qz.x, Qz.y, Qz.z, m, cell, cursor, g->sx, g->sy, g->sz,
-                                                                       g->perm);
+    grid_scatter_kernel<<<(unsigned)((m + kWG - 1) / kWG), kWG, 0, s>>>(Qz.x, Qz.y, Qz.z, m, cell, cursor, g->rec, g->perm);
     GRID_TRY(hipGetLastError());
     GRID_TRY(hipStreamSynchronize(s));   // the temporaries are freed below
     g->ok = true;
@@ -514,16 +517,15 @@ hipError_t search_grid(hipStream_t s, Soa3 P, size_t n, const double *pc, const 
     const int row_cap = getenv("ICP_AMD_GRID_ROWCAP") ? atoi(getenv("ICP_AMD_GRID_ROWCAP")) : 64;
     const int eval_cap = getenv("ICP_AMD_GRID_EVALCAP") ? atoi(getenv("ICP_AMD_GRID_EVALCAP")) : 768;
     uint32_t *cnt = sc ? sc->count2 + sc->parity : nullptr, *cnt_next = sc ? sc->count2 + (sc->parity ^ 1) : nullptr;
-    search_grid_kernel<<<(unsigned)((n + kWG - 1) / kWG), kWG, 0, s>>>(P.x, P.y, P.z, pc, n, g.d, g.start, g.sx, g.sy, g.sz, g.perm,
-                                                                      Qz.x, Qz.y, Qz.z, (unsigned)m, idx_prev, order, row_cap,
+    search_grid_kernel<<<(unsigned)((n + kWG - 1) / kWG), kWG, 0, s>>>(P.x, P.y, P.z, pc, n, g.d, g.start, g.rec, Qz.x, Qz.y, Qz.z,
+                                                                      Qz.rec, (unsigned)m, idx_prev, order, row_cap,
                                                                       (unsigned)eval_cap, cnt, sc ? sc->list : nullptr, out_key,
                                                                       out_idx);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || !sc) return e;
     size_t wgs = n < 2048 ? n : 2048;
-    search_grid_overflow_kernel<<<(unsigned)wgs, kWG, 0, s>>>(P.x, P.y, P.z, pc, g.d, g.start, g.sx, g.sy, g.sz, g.perm, Qz.x, Qz.y,
-                                                             Qz.z, (unsigned)m, cnt, cnt_next, sc->list, sc->host_count, out_key,
-                                                             out_idx);
+    search_grid_overflow_kernel<<<(unsigned)wgs, kWG, 0, s>>>(P.x, P.y, P.z, pc, g.d, g.start, g.rec, Qz.x, Qz.y, Qz.z, Qz.rec,
+                                                             (unsigned)m, cnt, cnt_next, sc->list, sc->host_count, out_key, out_idx);
     sc->parity ^= 1;
     return hipGetLastError();
 }

@@ -19,7 +19,12 @@ constexpr size_t kSplitGran = 64;  // target splits are whole multiples of this 
 
 struct Soa3 {            // device SoA view of a cloud
     double *x, *y, *z;
+    // optional row-major copy for random access by index, rec[j] = {x, y, z, unused}: one 32-byte record (one cache
+    // line touched) per gathered point instead of three
+    double4 *rec = nullptr;
 };
+// rec[j] = {x[j], y[j], z[j], 0} for j < rows
+hipError_t build_rec(hipStream_t s, Soa3 soa, size_t rows);
 
 // Sum of each coordinate over 1024-row chunks: partial[chunk][3] (fixed reduction order).
 // src is row-major AoS (n x 3) when aos != nullptr, else the SoA view.
@@ -65,8 +70,7 @@ struct Grid {
     size_t cells = 0;
     uint32_t *start = nullptr;   // cells + 1: first sorted position of each cell, cell id = (cz*dim[1] + cy)*dim[0] + cx
     uint32_t *perm = nullptr;    // m: original index of each sorted target
-    double *store = nullptr;     // 3 * m: sorted coordinates (SoA)
-    double *sx = nullptr, *sy = nullptr, *sz = nullptr;
+    double4 *rec = nullptr;      // m: sorted targets as {x, y, z, original index (integer bit pattern)}
     bool ok = false;             // false: the cloud has non-finite coordinates, use a brute-force variant
 };
 // Builds the grid of Qz[0, m) (allocates; synchronises the stream).  Non-finite coordinates: success with ok = false.

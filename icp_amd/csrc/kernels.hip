@@ -511,7 +511,8 @@ template <bool MERGE>
 __global__ __launch_bounds__(kWG) void cov_kernel(const double *__restrict__ px, const double *__restrict__ py,
                                                   const double *__restrict__ pz, size_t n, size_t n_pad,
                                                   const double *__restrict__ pc, const double *__restrict__ qx,
-                                                  const double *__restrict__ qy, const double *__restrict__ qz, size_t m,
+                                                  const double *__restrict__ qy, const double *__restrict__ qz,
+                                                  const double4 *__restrict__ qrec4, size_t m,
                                                   int q_splits, const double *__restrict__ keys,
                                                   const uint32_t *__restrict__ idxs, const uint32_t *__restrict__ idx_in,
                                                   uint32_t *__restrict__ idx_out, double *__restrict__ partial)
@@ -544,7 +545,13 @@ __global__ __launch_bounds__(kWG) void cov_kernel(const double *__restrict__ px,
             }
             if (j < m) {
                 const double p0 = px[i] - c0, p1 = py[i] - c1, p2 = pz[i] - c2;
-                const double q0 = qx[j], q1 = qy[j], q2 = qz[j];
+                double q0, q1, q2;
+                if (qrec4) {   // one 32-byte record per gathered target
+                    const double4 v = qrec4[j];
+                    q0 = v.x; q1 = v.y; q2 = v.z;
+                } else {
+                    q0 = qx[j]; q1 = qy[j]; q2 = qz[j];
+                }
                 acc[0] += q0 * p0; acc[1] += q0 * p1; acc[2] += q0 * p2;
                 acc[3] += q1 * p0; acc[4] += q1 * p1; acc[5] += q1 * p2;
                 acc[6] += q2 * p0; acc[7] += q2 * p1; acc[8] += q2 * p2;
@@ -991,6 +998,20 @@ hipError_t aos_to_soa(hipStream_t s, const double *aos, size_t n, size_t n_pad, 
     return hipGetLastError();
 }
 
+__global__ __launch_bounds__(kWG) void build_rec_kernel(const double *__restrict__ x, const double *__restrict__ y,
+                                                        const double *__restrict__ z, size_t rows, double4 *__restrict__ rec)
+{
+    const size_t i = (size_t)blockIdx.x * kWG + threadIdx.x;
+    if (i < rows) rec[i] = make_double4(x[i], y[i], z[i], 0.0);
+}
+
+hipError_t build_rec(hipStream_t s, Soa3 soa, size_t rows)
+{
+    if (rows == 0 || !soa.rec) return hipErrorInvalidValue;
+    build_rec_kernel<<<blocks_for(rows, kWG), kWG, 0, s>>>(soa.x, soa.y, soa.z, rows, soa.rec);
+    return hipGetLastError();
+}
+
 hipError_t soa_to_aos(hipStream_t s, Soa3 in, size_t n, double *aos)
 {
     if (n == 0) return hipSuccess;
@@ -1076,7 +1097,7 @@ hipError_t merge_cov(hipStream_t s, Soa3 P, size_t n, size_t n_pad, const double
                      const double *keys, const uint32_t *idxs, uint32_t *idx_out, double *partial)
 {
     if (n == 0) return hipSuccess;
-    cov_kernel<true><<<blocks_for(n, kChunk), kWG, 0, s>>>(P.x, P.y, P.z, n, n_pad, pc, Qz.x, Qz.y, Qz.z, m, q_splits, keys,
+    cov_kernel<true><<<blocks_for(n, kChunk), kWG, 0, s>>>(P.x, P.y, P.z, n, n_pad, pc, Qz.x, Qz.y, Qz.z, Qz.rec, m, q_splits, keys,
                                                            idxs, nullptr, idx_out, partial);
     return hipGetLastError();
 }
@@ -1085,7 +1106,7 @@ hipError_t cov_from_idx(hipStream_t s, Soa3 P, size_t n, const double *pc, Soa3 
                         double *partial)
 {
     if (n == 0) return hipSuccess;
-    cov_kernel<false><<<blocks_for(n, kChunk), kWG, 0, s>>>(P.x, P.y, P.z, n, 0, pc, Qz.x, Qz.y, Qz.z, m, 1, nullptr, nullptr,
+    cov_kernel<false><<<blocks_for(n, kChunk), kWG, 0, s>>>(P.x, P.y, P.z, n, 0, pc, Qz.x, Qz.y, Qz.z, Qz.rec, m, 1, nullptr, nullptr,
                                                             idx, nullptr, partial);
     return hipGetLastError();
 }
