@@ -29,7 +29,7 @@ hipError_t build_rec(hipStream_t s, Soa3 soa, size_t rows);
 // Sum of each coordinate over 1024-row chunks: partial[chunk][3] (fixed reduction order).
 // src is row-major AoS (n x 3) when aos != nullptr, else the SoA view.
 hipError_t colsum_partials(hipStream_t s, const double *aos, Soa3 soa, size_t n, double *partial);
-// out[k] = (sum over `count` partials in index order)[k] / denom     (k < 3)
+// out[k] = (fixed-order sum over `count` partials: groups of 32 in index order, then the group sums in order)[k] / denom
 hipError_t finalize_centroid(hipStream_t s, const double *partial, size_t count, double denom, double *out3);
 // AoS -> SoA, padded rows [n, n_pad) set to `pad`.  If c3 != nullptr subtracts c3[k] (the centring of Q).
 hipError_t aos_to_soa(hipStream_t s, const double *aos, size_t n, size_t n_pad, const double *c3, double pad, Soa3 out);
@@ -104,7 +104,7 @@ hipError_t merge_cov(hipStream_t s, Soa3 P, size_t n, size_t n_pad, const double
 hipError_t cov_from_idx(hipStream_t s, Soa3 P, size_t n, const double *pc, Soa3 Qz, size_t m, const uint32_t *idx,
                         double *partial);
 
-// Sum `count` cov partials in index order, 3x3 SVD, R = U V^T, t = Qc - Pc R^T.
+// Sum `count` cov partials in the same fixed order, 3x3 SVD, R = U V^T, t = Qc - Pc R^T.
 // out: [0..8] cov, [9..11] S, [12..20] R, [21..23] t, [24] rms, [25..27] Pc copy  (28 doubles)
 constexpr int kSolveW = 28;
 hipError_t solve(hipStream_t s, const double *partial, size_t count, const double *pc, const double *qc,

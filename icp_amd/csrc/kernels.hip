@@ -50,20 +50,36 @@ __device__ __forceinline__ double block_sum(double (&v)[NV], double *smem)
     return tot;
 }
 
-// In-index-order sum of `count` partial records of W doubles; thread k < W ends with the total of column k.
-// Records are staged through LDS in batches so that the dependent add chain never waits on HBM.
+// Fixed-order sum of `count` partial records of W doubles; thread k < W ends with the total of column k.
+// Order (independent of the launch geometry and of how the records were distributed over GPUs): groups of kSumGroup
+// consecutive records are summed in index order, then the group sums are summed in index order.  Up to kSumGroup
+// records that is the plain in-order sum.  The groups of one pass are summed by different threads at the same time, so
+// the dependent add chain is kSumGroup + count / kSumGroup long instead of count.
+constexpr int kSumGroup = 32;
 template <int W>
-__device__ __forceinline__ double ordered_sum(const double *__restrict__ partial, size_t count, double *stage /*[kStage]*/)
+__device__ __forceinline__ double ordered_sum(const double *__restrict__ partial, size_t count, double *stage /*[>= 256]*/)
 {
-    constexpr int kStageRecs = 256;
+    constexpr int GP = kWG / W;   // groups per pass
+    const int col = threadIdx.x % W, gl = threadIdx.x / W;
+    const size_t groups = (count + kSumGroup - 1) / kSumGroup;
     double acc = 0.0;
-    for (size_t r0 = 0; r0 < count; r0 += kStageRecs) {
-        const int recs = (int)((count - r0 < (size_t)kStageRecs) ? (count - r0) : (size_t)kStageRecs);
+    for (size_t g0 = 0; g0 < groups; g0 += GP) {
+        double s = 0.0;
+        const size_t g = g0 + (size_t)gl;
+        if (gl < GP && g < groups) {
+            const size_t r0 = g * kSumGroup;
+            const int recs = (int)((count - r0 < (size_t)kSumGroup) ? (count - r0) : (size_t)kSumGroup);
+            const double *src = partial + r0 * W + col;
+#pragma unroll 8
+            for (int r = 0; r < recs; ++r) s += src[(size_t)r * W];
+        }
         __syncthreads();
-        for (int k = threadIdx.x; k < recs * W; k += kWG) stage[k] = partial[r0 * W + k];
+        if (gl < GP) stage[gl * W + col] = s;
         __syncthreads();
-        if (threadIdx.x < W)
-            for (int r = 0; r < recs; ++r) acc += stage[r * W + threadIdx.x];
+        if (threadIdx.x < W) {
+            const int ng = (int)((groups - g0 < (size_t)GP) ? (groups - g0) : (size_t)GP);
+            for (int k = 0; k < ng; ++k) acc += stage[k * W + threadIdx.x];
+        }
     }
     return acc;
 }
