@@ -12,7 +12,7 @@ import numpy as np
 from . import _lib
 from ._lib import METHODS, SEARCH, IcpAmdError, Options, Trace, check, lib
 
-__all__ = ["icp_gpu_optimized", "icp_gpu", "icp_gpu_multi", "icp_gpu_batch", "Batch", "Engine", "read_csv", "write_cloud", "euclidian_distance",
+__all__ = ["icp_gpu_optimized", "icp_gpu", "icp_gpu_multi", "icp_gpu_batch", "Batch", "Engine", "read_csv", "read_csv_mt", "read_cloud", "write_cloud", "write_cloud_binary", "euclidian_distance",
            "correspondences", "cross_cov", "centroid", "solve", "apply", "rows_per_rank", "chunks_per_rank",
            "IcpAmdError", "device_count"]
 
@@ -273,6 +273,33 @@ def read_csv(path):
     finally:
         lib().icp_amd_free(out)
     return a.reshape(nl.value, nc.value), hdr.value.decode(errors="replace")
+
+
+def _read(fn, path, *extra):
+    out = C.POINTER(C.c_double)()
+    nl, nc = C.c_size_t(), C.c_size_t()
+    hdr = C.create_string_buffer(4096)
+    check(fn(str(path).encode(), *extra, C.byref(out), C.byref(nl), C.byref(nc), hdr, C.c_size_t(4096)))
+    try:
+        a = np.ctypeslib.as_array(out, shape=(nl.value * nc.value,)).copy() if nl.value * nc.value else np.empty(0)
+    finally:
+        lib().icp_amd_free(out)
+    return a.reshape(nl.value, nc.value), hdr.value.decode(errors="replace")
+
+
+def read_csv_mt(path, threads=0):
+    """icp_amd_read_csv with the lines spread over host threads: same values, shapes and errors."""
+    return _read(lib().icp_amd_read_csv_mt, path, C.c_int(threads))
+
+
+def read_cloud(path):
+    """*.npy / *.f64 (raw fp64 x 3) / CSV by file name."""
+    return _read(lib().icp_amd_read_cloud, path)
+
+
+def write_cloud_binary(path, A):
+    A = np.ascontiguousarray(A, dtype=np.float64)
+    check(lib().icp_amd_write_cloud_binary(str(path).encode(), _p(A), C.c_size_t(A.shape[0]), C.c_size_t(A.shape[1])))
 
 
 def write_cloud(path, A):

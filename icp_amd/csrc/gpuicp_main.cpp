@@ -23,7 +23,7 @@ static void runtime_assert(bool cond, const std::string &msg)
 static std::vector<double> load(const char *path, size_t &rows, size_t &cols)
 {
     double *a = nullptr;
-    const int rc = icp_amd_read_csv(path, &a, &rows, &cols, nullptr, 0);
+    const int rc = icp_amd_read_cloud(path, &a, &rows, &cols, nullptr, 0);   // CSV like readCSV; *.npy / *.f64 by name
     runtime_assert(rc == ICP_AMD_OK, icp_amd_last_error());
     std::vector<double> v(a, a + rows * cols);
     icp_amd_free(a);
@@ -67,5 +67,7 @@ int main(int argc, char **argv)
     runtime_assert(Pl == Ql, "element_wise_reduce requires arrays to be broadcastable");
     std::cout << "Squared actual mean diff: " << icp_amd_euclidian_distance(Q.data(), P_res.data(), Ql, 3) << std::endl;
     runtime_assert(icp_amd_write_cloud("point_cloud_result", P_res.data(), Pl, 3) == ICP_AMD_OK, "could not write point_cloud_result");
+    if (const char *bin = getenv("ICP_AMD_RESULT_FILE"))   // additive: the result in full precision (*.npy / *.f64)
+        runtime_assert(icp_amd_write_cloud_binary(bin, P_res.data(), Pl, 3) == ICP_AMD_OK, icp_amd_last_error());
     return 0;
 }

@@ -175,6 +175,16 @@ int    icp_amd_read_csv(const char *path, double **out, size_t *nblines, size_t 
 void   icp_amd_free(void *p);
 /* CPUMatrix::write_in_file / operator<< (src/libalg/CPUMatrix.cpp:81-94,323-327) */
 int    icp_amd_write_cloud(const char *path, const double *A, size_t rows, size_t cols);
+/* The same parse as icp_amd_read_csv (identical values, shapes and errors) with the lines spread over `threads` host
+ * threads (0 = one per core, at most 16): readCSV costs seconds on the 60 MB files of a 1M-point cloud. */
+int    icp_amd_read_csv_mt(const char *path, int threads, double **out, size_t *nblines, size_t *nbcols, char *header,
+                           size_t header_cap);
+/* Cloud by file name (no counterpart in the reference, whose only format is CSV): *.npy (little-endian float64, C order,
+ * 1-D or 2-D), *.f64 (raw little-endian float64, 3 columns), anything else = CSV as above.  ICP_AMD_CSV_THREADS=1 forces
+ * the serial parser. */
+int    icp_amd_read_cloud(const char *path, double **out, size_t *nblines, size_t *nbcols, char *header, size_t header_cap);
+/* Result in full precision: *.npy or *.f64 by file name (icp_amd_write_cloud stays the reference's 6-digit text). */
+int    icp_amd_write_cloud_binary(const char *path, const double *A, size_t rows, size_t cols);
 /* CPUMatrix::euclidianDistance (src/libalg/CPUMatrix.cpp:291-295) on two rows x cols clouds (host, fp64) */
 double icp_amd_euclidian_distance(const double *A, const double *B, size_t rows, size_t cols);
 

@@ -72,6 +72,74 @@ def test_read_csv_matches_reference_behaviour(tmp_path):
         assert a.shape == (2903, 5)
 
 
+def _same_outcome(path):
+    """serial and threaded parsers: same array + header, or the same error text"""
+    outs = []
+    for fn in (lambda: icp_amd.read_csv(path), lambda: icp_amd.read_csv_mt(path, 1), lambda: icp_amd.read_csv_mt(path, 5),
+               lambda: icp_amd.read_csv_mt(path, 0), lambda: icp_amd.read_cloud(path)):
+        try:
+            a, h = fn()
+            outs.append(("ok", a.shape, a.tobytes(), h))
+        except icp_amd.IcpAmdError as e:
+            outs.append(("err", str(e)))
+    assert all(o == outs[0] for o in outs[1:]), (path, [o[:2] for o in outs])
+    return outs[0]
+
+
+def test_threaded_csv_parser_is_the_serial_one(tmp_path):
+    """identical values, shapes, headers and errors, file by file."""
+    rng = np.random.RandomState(4)
+    def w(name, text):
+        p = tmp_path / name
+        p.write_bytes(text.encode())
+        return p
+    A = rng.uniform(-1e3, 1e3, (40000, 3))
+    body = "".join("%.17g,%.17g,%.17g\n" % tuple(r) for r in A)          # ~2.3 MB: several 64 KB pieces per thread
+    kind, shape, data, h = _same_outcome(w("big.csv", "Points_0,Points_1,Points_2\n" + body))
+    assert kind == "ok" and shape == (40000, 3) and data == A.tobytes() and h == "Points_0,Points_1,Points_2\n"
+    assert _same_outcome(w("nonl.csv", body[:-1]))[1] == (40000, 3)        # no newline at the end of the file
+    assert _same_outcome(w("crlf.csv", body.replace("\n", "\r\n")))[1] == (40000, 3)
+    lines = body.split("\n")[:-1]
+    for k, (name, mutate) in enumerate((
+            ("ragged_late", lambda L: L[:30000] + ["1,2"] + L[30000:]),
+            ("ragged_early", lambda L: L[:3] + ["1,2,3,4"] + L[3:]),
+            ("nan_text", lambda L: L[:20000] + ["1,abc,3"] + L[20000:]),
+            ("blank_middle", lambda L: L[:25000] + [""] + L[25000:]),
+            ("blank_end", lambda L: L + [""]),
+            ("spaces", lambda L: L[:10] + [" 1.5 , 2.5 ,3abc", ",,4,,5,6,"] + L[10:]),
+            ("two_errors", lambda L: L[:100] + ["1,2"] + L[100:35000] + ["x,y,z"] + L[35000:]))):
+        out = _same_outcome(w("m%d.csv" % k, "\n".join(mutate(lines)) + "\n"))
+        assert (out[0] == "ok") == (name == "spaces"), name
+    for text in ("", "\n", "a,b,c\n", "1,2,3", "1,2,3\n", ",\n1,2\n", "h1,h2\n1,2\n3,4\n"):
+        _same_outcome(w("tiny.csv", text))
+    if os.path.isdir(REF_DATA):
+        for name in ("30points_notebook_P.txt", "icp/cow_tr1.txt", "icp/cow_tr2.txt", "icp/horse_ref.txt"):
+            assert _same_outcome(REF_DATA + "/" + name)[0] == "ok"
+
+
+def test_binary_clouds_round_trip(tmp_path):
+    rng = np.random.RandomState(6)
+    A = rng.standard_normal((1234, 3)) * 10.0 ** rng.uniform(-200, 200, (1234, 3))
+    for name in ("c.npy", "c.f64"):
+        icp_amd.write_cloud_binary(tmp_path / name, A)
+        B, _ = icp_amd.read_cloud(tmp_path / name)
+        assert B.shape == A.shape and B.tobytes() == A.tobytes()
+    assert np.array_equal(np.load(tmp_path / "c.npy"), A)                 # a real .npy, both ways
+    np.save(tmp_path / "n.npy", A)
+    assert np.array_equal(icp_amd.read_cloud(tmp_path / "n.npy")[0], A)
+    np.save(tmp_path / "v.npy", A[:, 0].copy())
+    assert icp_amd.read_cloud(tmp_path / "v.npy")[0].shape == (1234, 1)
+    for bad, arr in (("f4.npy", A.astype(np.float32)), ("fo.npy", np.asfortranarray(A)), ("3d.npy", A.reshape(617, 2, 3))):
+        np.save(tmp_path / bad, arr)
+        with pytest.raises(icp_amd.IcpAmdError):
+            icp_amd.read_cloud(tmp_path / bad)
+    (tmp_path / "odd.f64").write_bytes(b"\0" * 25)
+    with pytest.raises(icp_amd.IcpAmdError):
+        icp_amd.read_cloud(tmp_path / "odd.f64")
+    with pytest.raises(icp_amd.IcpAmdError):
+        icp_amd.write_cloud_binary(tmp_path / "c.txt", A)
+
+
 def test_write_cloud_and_report_format(tmp_path):
     g = golden("c1_30pts")
     out = tmp_path / "point_cloud_result"
