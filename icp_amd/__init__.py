@@ -155,6 +155,20 @@ class Engine:
         check(lib().icp_amd_kernel_ms(self._h, C.byref(avg), C.byref(tot), C.byref(cnt)))
         return avg.value, tot.value, cnt.value
 
+    def set_reject_distance(self, dmax):
+        check(lib().icp_amd_set_reject_distance(self._h, C.c_double(dmax)))
+
+    def iterate_until(self, max_iters, rot_tol, trans_tol, check_every=1):
+        done = C.c_uint()
+        check(lib().icp_amd_iterate_until(self._h, C.c_uint(max_iters), C.c_double(rot_tol), C.c_double(trans_tol),
+                                          C.c_uint(check_every), C.byref(done)))
+        return done.value
+
+    def last_motion(self):
+        a, b, c = C.c_double(), C.c_double(), C.c_double()
+        check(lib().icp_amd_get_last_motion(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return dict(pairs_used=a.value, delta_rot=b.value, delta_trans=c.value)
+
     def grid_stats(self):
         a, b, c = C.c_uint(), C.c_uint(), C.c_uint()
         check(lib().icp_amd_grid_stats(self._h, C.byref(a), C.byref(b), C.byref(c)))

@@ -134,7 +134,8 @@ struct icp_amd_engine {
     // partials
     double *cov_part = nullptr, *cen_part = nullptr;  // world*cpr*{12,3}; own or caller's gather buffers
     bool own_part = false;
-    double *rec = nullptr;      // kSolveW doubles: outputs of the most recent solve
+    double *rec = nullptr;      // kSolveW doubles: outputs of the most recent solve; + 3: pairs used, |R - I|, |motion of Pc|
+    double reject_d2 = std::numeric_limits<double>::infinity();   // f-4: pairs farther apart get weight 0 (inf = reference)
 
     bool have_target = false, have_source = false, cen_ready = false;
 
@@ -180,7 +181,7 @@ extern "C" int icp_amd_create(icp_amd_engine **out, const icp_amd_options *opt_i
     }
     hipError_t er = hipMalloc(&e->qc, 3 * sizeof(double));
     if (er == hipSuccess) er = hipMalloc(&e->pc, 3 * sizeof(double));
-    if (er == hipSuccess) er = hipMalloc(&e->rec, kSolveW * sizeof(double));
+    if (er == hipSuccess) er = hipMalloc(&e->rec, (kSolveW + 3) * sizeof(double));
     if (er != hipSuccess) { icp_amd_destroy(e); return fail(ICP_AMD_ENOMEM, "hipMalloc: %s", hipGetErrorString(er)); }
     *out = e;
     return ICP_AMD_OK;
@@ -509,7 +510,8 @@ extern "C" int icp_amd_step_search(icp_amd_engine *e)
             HIPCHK(search(e->stream, e->variant, e->ppl, e->cb, e->P, e->n_pad, e->pc, e->Qz, e->m, e->m_pad, splits,
                           seed ? e->idx : nullptr, e->keys, e->idxs));
         if (e->opt.kernel_timing) HIPCHK(hipEventRecord(b, e->stream));
-        HIPCHK(merge_cov(e->stream, e->P, e->n, e->n_pad, e->pc, e->Qz, e->m, splits, e->keys, e->idxs, e->idx, cov_slot));
+        HIPCHK(merge_cov(e->stream, e->P, e->n, e->n_pad, e->pc, e->Qz, e->m, splits, e->keys, e->idxs, e->idx, e->reject_d2,
+                         cov_slot));
         e->have_prev = true;
     }
     return ICP_AMD_OK;
@@ -519,7 +521,9 @@ extern "C" int icp_amd_step_update(icp_amd_engine *e)
 {
     if (!e || !e->have_source) return fail(ICP_AMD_ESTATE, "icp_amd_step_update: no source cloud");
     HIPCHK(hipSetDevice(e->opt.device));
-    HIPCHK(solve(e->stream, e->cov_part, e->total_chunks, e->pc, e->qc, (double)e->n_global, e->rec));
+    const bool rejecting = e->reject_d2 < std::numeric_limits<double>::infinity();
+    HIPCHK(solve(e->stream, e->cov_part, e->total_chunks, e->pc, e->qc, rejecting ? -1.0 : (double)e->n_global, e->rec,
+                 e->rec + kSolveW));
     double *cen_slot = e->cen_part + (size_t)e->opt.rank * e->cpr * kCenW;
     HIPCHK(apply(e->stream, e->P, e->n, e->rec, cen_slot));
     return ICP_AMD_OK;
@@ -536,6 +540,52 @@ extern "C" int icp_amd_iterate(icp_amd_engine *e, unsigned iters)
         RCCHK(icp_amd_step_update(e));
     }
     return ICP_AMD_OK;
+}
+
+// ---- f-4: the hooks the reference stubs out (weight kernel / exclude_indices, src/cpu/icp.cpp:108-124; the unused
+//      per-iteration norm, :213).  Off by default: results then equal the reference's.
+extern "C" int icp_amd_set_reject_distance(icp_amd_engine *e, double dmax)
+{
+    if (!e) return fail(ICP_AMD_EINVAL, "icp_amd_set_reject_distance: NULL engine");
+    if (dmax != dmax) return fail(ICP_AMD_EINVAL, "icp_amd_set_reject_distance: NaN");
+    e->reject_d2 = (dmax > 0.0 && dmax < std::numeric_limits<double>::infinity()) ? dmax * dmax
+                                                                                  : std::numeric_limits<double>::infinity();
+    return ICP_AMD_OK;
+}
+
+extern "C" int icp_amd_get_last_motion(icp_amd_engine *e, double *pairs_used, double *delta_rot, double *delta_trans)
+{
+    if (!e) return fail(ICP_AMD_EINVAL, "icp_amd_get_last_motion: NULL engine");
+    HIPCHK(hipSetDevice(e->opt.device));
+    double h[3];
+    HIPCHK(hipMemcpyAsync(h, e->rec + kSolveW, sizeof h, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    if (pairs_used) *pairs_used = h[0];
+    if (delta_rot) *delta_rot = h[1];
+    if (delta_trans) *delta_trans = h[2];
+    return ICP_AMD_OK;
+}
+
+extern "C" int icp_amd_iterate_until(icp_amd_engine *e, unsigned max_iters, double rot_tol, double trans_tol,
+                                     unsigned check_every, unsigned *iters_done)
+{
+    if (!e) return fail(ICP_AMD_EINVAL, "icp_amd_iterate_until: NULL engine");
+    if (!(rot_tol >= 0.0) || !(trans_tol >= 0.0)) return fail(ICP_AMD_EINVAL, "icp_amd_iterate_until: tolerances must be >= 0");
+    if (check_every == 0) check_every = 1;
+    unsigned done = 0;
+    int rc = ICP_AMD_OK;
+    while (done < max_iters) {
+        const unsigned step = (max_iters - done < check_every) ? max_iters - done : check_every;
+        rc = icp_amd_iterate(e, step);
+        if (rc != ICP_AMD_OK) break;
+        done += step;
+        double dr = 0.0, dt = 0.0;
+        rc = icp_amd_get_last_motion(e, nullptr, &dr, &dt);   // the only host synchronisation of the loop
+        if (rc != ICP_AMD_OK) break;
+        if (dr <= rot_tol && dt <= trans_tol) break;
+    }
+    if (iters_done) *iters_done = done;
+    return rc;
 }
 
 extern "C" int icp_amd_iterate_timed(icp_amd_engine *e, unsigned iters, double *elapsed_ms)
@@ -1031,7 +1081,7 @@ extern "C" int icp_amd_correspondences(const double *P, size_t n, const double P
                       idxs.as<uint32_t>()));
     }
     HIPCHK(merge_cov(s, dP, n, n_pad, pc.as<double>(), dQ, m, q_splits, keys.as<double>(), idxs.as<uint32_t>(),
-                     out.as<uint32_t>(), part.as<double>()));
+                     out.as<uint32_t>(), std::numeric_limits<double>::infinity(), part.as<double>()));
     HIPCHK(hipMemcpyAsync(idx, out.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     return ICP_AMD_OK;
@@ -1060,7 +1110,7 @@ extern "C" int icp_amd_cross_cov(const double *P, size_t n, const double Pc[3], 
     HIPCHK(part.alloc(chunks * kCovW * sizeof(double)));
     HIPCHK(rec.alloc(kSolveW * sizeof(double)));
     HIPCHK(cov_from_idx(s, dP, n, pc.as<double>(), dQ, m, di.as<uint32_t>(), part.as<double>()));
-    HIPCHK(solve(s, part.as<double>(), chunks, pc.as<double>(), qc.as<double>(), (double)n, rec.as<double>()));
+    HIPCHK(solve(s, part.as<double>(), chunks, pc.as<double>(), qc.as<double>(), (double)n, rec.as<double>(), nullptr));
     HIPCHK(hipMemcpyAsync(cov, rec.p, 9 * sizeof(double), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     return ICP_AMD_OK;
@@ -1100,7 +1150,7 @@ extern "C" int icp_amd_solve(const double cov[9], const double Pc[3], const doub
     HIPCHK(hipMemcpyAsync(part.p, h, sizeof h, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(pc.p, Pc, 3 * sizeof(double), hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(qc.p, Qc, 3 * sizeof(double), hipMemcpyHostToDevice, s));
-    HIPCHK(solve(s, part.as<double>(), 1, pc.as<double>(), qc.as<double>(), 1.0, rec.as<double>()));
+    HIPCHK(solve(s, part.as<double>(), 1, pc.as<double>(), qc.as<double>(), 1.0, rec.as<double>(), nullptr));
     double r[kSolveW];
     HIPCHK(hipMemcpyAsync(r, rec.p, sizeof r, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));

@@ -98,8 +98,10 @@ hipError_t grid_order(hipStream_t s, Soa3 P, size_t n, uint32_t *order);
 // Merge the splits (lowest index among equal keys), write idx[n], and reduce q (x) p per 1024-row chunk
 // into partial[chunk][12].
 hipError_t merge_cov(hipStream_t s, Soa3 P, size_t n, size_t n_pad, const double *pc, Soa3 Qz, size_t m,
-                     int q_splits, const double *keys, const uint32_t *idxs, uint32_t *idx_out,
+                     int q_splits, const double *keys, const uint32_t *idxs, uint32_t *idx_out, double reject_d2,
                      double *partial);
+// reject_d2: pairs farther apart than this (squared, the oracle's un-fused d^2) get weight 0 in the sums; +inf = none.
+// partial slots: [0..8] cov, [9] sum of d^2, [10] number of pairs that entered the sums, [11] spare.
 // cov partials from a given idx (stage-level entry).
 hipError_t cov_from_idx(hipStream_t s, Soa3 P, size_t n, const double *pc, Soa3 Qz, size_t m, const uint32_t *idx,
                         double *partial);
@@ -107,8 +109,10 @@ hipError_t cov_from_idx(hipStream_t s, Soa3 P, size_t n, const double *pc, Soa3 
 // Sum `count` cov partials in the same fixed order, 3x3 SVD, R = U V^T, t = Qc - Pc R^T.
 // out: [0..8] cov, [9..11] S, [12..20] R, [21..23] t, [24] rms, [25..27] Pc copy  (28 doubles)
 constexpr int kSolveW = 28;
+// n_global <= 0: rms over the pairs counted in slot 10.  extra (optional, 3 doubles): pairs used, max |R - I|,
+// max |R Pc + t - Pc| -- how far this iteration's motion is from the identity.
 hipError_t solve(hipStream_t s, const double *partial, size_t count, const double *pc, const double *qc,
-                 double n_global, double *out);
+                 double n_global, double *out, double *extra);
 // P <- P R^T + t (R, t read from the solve record) and per-chunk sums of the new P.
 hipError_t apply(hipStream_t s, Soa3 P, size_t n, const double *solve_rec, double *cen_partial);
 

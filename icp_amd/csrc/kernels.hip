@@ -531,7 +531,8 @@ __global__ __launch_bounds__(kWG) void cov_kernel(const double *__restrict__ px,
                                                   const double4 *__restrict__ qrec4, size_t m,
                                                   int q_splits, const double *__restrict__ keys,
                                                   const uint32_t *__restrict__ idxs, const uint32_t *__restrict__ idx_in,
-                                                  uint32_t *__restrict__ idx_out, double *__restrict__ partial)
+                                                  uint32_t *__restrict__ idx_out, double reject_d2,
+                                                  double *__restrict__ partial)
 {
     __shared__ double smem[4 * kCovW];
     const double c0 = pc[0], c1 = pc[1], c2 = pc[2];
@@ -568,10 +569,16 @@ __global__ __launch_bounds__(kWG) void cov_kernel(const double *__restrict__ px,
                 } else {
                     q0 = qx[j]; q1 = qy[j]; q2 = qz[j];
                 }
-                acc[0] += q0 * p0; acc[1] += q0 * p1; acc[2] += q0 * p2;
-                acc[3] += q1 * p0; acc[4] += q1 * p1; acc[5] += q1 * p2;
-                acc[6] += q2 * p0; acc[7] += q2 * p1; acc[8] += q2 * p2;
-                acc[9] += d2_exact(p0, p1, p2, q0, q1, q2);
+                // the weight hook of compute_cross_variance (src/cpu/icp.cpp:108-131: weight = kernel(p - q), a constant 1
+                // there) as a hard threshold on the pair's distance: weight 1 up to reject_d2 (+inf = the reference), else 0
+                const double d = d2_exact(p0, p1, p2, q0, q1, q2);
+                if (d <= reject_d2) {
+                    acc[0] += q0 * p0; acc[1] += q0 * p1; acc[2] += q0 * p2;
+                    acc[3] += q1 * p0; acc[4] += q1 * p1; acc[5] += q1 * p2;
+                    acc[6] += q2 * p0; acc[7] += q2 * p1; acc[8] += q2 * p2;
+                    acc[9] += d;
+                    acc[10] += 1.0;   // pairs that entered the sums
+                }
             }
         }
     }
@@ -673,7 +680,7 @@ __device__ void solve_record(const double *tot, const double *pc, const double *
 
 __global__ __launch_bounds__(kWG) void solve_kernel(const double *__restrict__ partial, size_t count,
                                                     const double *__restrict__ pc, const double *__restrict__ qc,
-                                                    double n_global, double *__restrict__ out)
+                                                    double n_global, double *__restrict__ out, double *__restrict__ extra)
 {
     __shared__ double stage[256 * kCovW];
     __shared__ double tot[kCovW];
@@ -681,7 +688,20 @@ __global__ __launch_bounds__(kWG) void solve_kernel(const double *__restrict__ p
     if (threadIdx.x < kCovW) tot[threadIdx.x] = acc;
     __syncthreads();
     if (threadIdx.x != 0) return;
-    solve_record(tot, pc, qc, n_global, out);
+    // n_global <= 0: the rms is taken over the pairs that entered the sums (distance rejection active)
+    solve_record(tot, pc, qc, n_global > 0.0 ? n_global : (tot[10] > 0.0 ? tot[10] : 1.0), out);
+    if (extra) {   // pairs used; how far this iteration's motion is from the identity (convergence test of the caller)
+        double dr = 0.0, dt = 0.0;
+        for (int k = 0; k < 9; ++k) dr = fmax(dr, fabs(out[12 + k] - ((k % 4 == 0) ? 1.0 : 0.0)));
+        // the motion of the cloud is x -> R x + t; about its centroid Pc the translation part is R Pc + t - Pc
+        for (int j = 0; j < 3; ++j) {
+            const double moved = ((out[12 + j * 3] * pc[0] + out[12 + j * 3 + 1] * pc[1]) + out[12 + j * 3 + 2] * pc[2]) + out[21 + j];
+            dt = fmax(dt, fabs(moved - pc[j]));
+        }
+        extra[0] = tot[10];
+        extra[1] = dr;
+        extra[2] = dt;
+    }
 }
 
 // One lane: cov -> SVD -> R, t; writes the 28-double record (layout in kernels.h).
@@ -1110,11 +1130,11 @@ hipError_t search_f32(hipStream_t s, int ppl, int cb, Soa3 P, size_t n_pad, cons
 }
 
 hipError_t merge_cov(hipStream_t s, Soa3 P, size_t n, size_t n_pad, const double *pc, Soa3 Qz, size_t m, int q_splits,
-                     const double *keys, const uint32_t *idxs, uint32_t *idx_out, double *partial)
+                     const double *keys, const uint32_t *idxs, uint32_t *idx_out, double reject_d2, double *partial)
 {
     if (n == 0) return hipSuccess;
     cov_kernel<true><<<blocks_for(n, kChunk), kWG, 0, s>>>(P.x, P.y, P.z, n, n_pad, pc, Qz.x, Qz.y, Qz.z, Qz.rec, m, q_splits, keys,
-                                                           idxs, nullptr, idx_out, partial);
+                                                           idxs, nullptr, idx_out, reject_d2, partial);
     return hipGetLastError();
 }
 
@@ -1123,14 +1143,14 @@ hipError_t cov_from_idx(hipStream_t s, Soa3 P, size_t n, const double *pc, Soa3 
 {
     if (n == 0) return hipSuccess;
     cov_kernel<false><<<blocks_for(n, kChunk), kWG, 0, s>>>(P.x, P.y, P.z, n, 0, pc, Qz.x, Qz.y, Qz.z, Qz.rec, m, 1, nullptr, nullptr,
-                                                            idx, nullptr, partial);
+                                                            idx, nullptr, INFINITY, partial);
     return hipGetLastError();
 }
 
 hipError_t solve(hipStream_t s, const double *partial, size_t count, const double *pc, const double *qc, double n_global,
-                 double *out)
+                 double *out, double *extra)
 {
-    solve_kernel<<<1, kWG, 0, s>>>(partial, count, pc, qc, n_global, out);
+    solve_kernel<<<1, kWG, 0, s>>>(partial, count, pc, qc, n_global, out, extra);
     return hipGetLastError();
 }
 

@@ -112,6 +112,19 @@ int icp_amd_set_target(icp_amd_engine *e, const double *Q_xyz, size_t m);
 int icp_amd_set_source(icp_amd_engine *e, const double *P_xyz, size_t n);
 /* Enqueue `iters` iterations (src/gpu/icp.cu:548-628); no host synchronisation.  world must be 1. */
 int icp_amd_iterate(icp_amd_engine *e, unsigned iters);
+/* ---- hooks the reference declares but leaves inert (weight kernel + exclude_indices of compute_cross_variance,
+ *      src/cpu/icp.cpp:108-124; the per-iteration norm it computes and drops, :213).  All off by default, in which case
+ *      results equal the reference's.
+ * Pairs farther apart than dmax get weight 0 in the cross-covariance (a hard-threshold `kernel`); dmax <= 0 or inf
+ * switches the rejection off.  Centroids, and so t = Qc - Pc R^T, stay over all points as in the reference. */
+int icp_amd_set_reject_distance(icp_amd_engine *e, double dmax);
+/* Iterates until one iteration's motion is within (rot_tol, trans_tol) of the identity -- max |R - I| and
+ * max |R Pc + t - Pc|, the displacement of the cloud's centroid -- or max_iters is reached; the test costs one host
+ * synchronisation every `check_every` iterations.  world must be 1. */
+int icp_amd_iterate_until(icp_amd_engine *e, unsigned max_iters, double rot_tol, double trans_tol, unsigned check_every,
+                          unsigned *iters_done);
+/* Of the most recent iteration: pairs that entered the covariance, max |R - I|, max |R Pc + t - Pc|.  Synchronises. */
+int icp_amd_get_last_motion(icp_amd_engine *e, double *pairs_used, double *delta_rot, double *delta_trans);
 /* Same, bracketed by hipEvents on the engine's stream; returns the elapsed device time. */
 int icp_amd_iterate_timed(icp_amd_engine *e, unsigned iters, double *elapsed_ms);
 /* P-sharded iteration in two phases; the caller all-gathers cov_gather after step_search and cen_gather
