@@ -108,6 +108,8 @@ struct icp_amd_engine {
     uint32_t *order = nullptr;  // n_pad: source rows in spatial order (GRID), valid when order_ok
     bool order_ok = false;
     GridScratch gscratch;       // queue of the points the grid search hands to its overflow kernel
+    double4 *p_rec = nullptr;   // 2 * n_pad: per source row {x,y,z,idx} {matched target} (GRID: one line per query)
+    double2 *grid_out = nullptr;  // n_pad (key, idx) records written by the grid search
     bool use_grid = false;      // planned: search on the grid (variant/ppl/q_splits then describe the brute-force fallback)
     bool grid_auto = false;     // the grid was chosen by AUTO: fall back to brute force while most points overflow
     unsigned bf_left = 0, bf_backoff = 0;   // AUTO: brute-force iterations left before the grid is tried again
@@ -198,6 +200,7 @@ extern "C" int icp_amd_destroy(icp_amd_engine *e)
     grid_free(&e->grid);
     free_dev(e->order);
     grid_scratch_free(&e->gscratch);
+    free_dev(e->p_rec); free_dev(e->grid_out);
     if (e->own_part) { free_dev(e->cov_part); free_dev(e->cen_part); }
     if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
@@ -216,6 +219,7 @@ static int ensure_stage(icp_amd_engine *e, size_t rows)
 }
 
 static int plan_search(icp_amd_engine *e);
+static int prepare_grid_source(icp_amd_engine *e);
 
 static const size_t kMaxRows = 0x7FFFFC00u;  // indices are 32-bit; padded sizes must fit too
 
@@ -263,7 +267,12 @@ extern "C" int icp_amd_set_target(icp_amd_engine *e, const double *Q, size_t m)
     grid_free(&e->grid);
     e->grid_built = false;
     e->have_prev = false;                       // correspondences into the previous target are no seed for this one
-    if (e->have_source) RCCHK(plan_search(e));  // the variant and the splits depend on the target
+    if (e->have_source) {
+        RCCHK(plan_search(e));  // the variant and the splits depend on the target
+        RCCHK(prepare_grid_source(e));
+        HIPCHK(hipStreamSynchronize(e->stream));
+        e->bf_left = e->bf_backoff = 0;
+    }
     return ICP_AMD_OK;
 }
 
@@ -361,6 +370,30 @@ static int plan_search(icp_amd_engine *e)
     return ICP_AMD_OK;
 }
 
+// Per-source state of the grid search (overflow queue, output records, the 64-byte row records, the spatial order);
+// built from the source cloud as it is now, whenever the source or the target is replaced.
+static int prepare_grid_source(icp_amd_engine *e)
+{
+    const size_t n = e->n, n_pad = e->n_pad;
+    e->order_ok = false;
+    e->P.rec = nullptr;
+    if (n && wants_grid(e)) {
+        if (!e->gscratch.list) HIPCHK(grid_scratch_alloc(n_pad, &e->gscratch));
+        if (!e->grid_out) HIPCHK(hipMalloc(&e->grid_out, n_pad * sizeof(double2)));
+        if (env_int("ICP_AMD_GRID_SRCREC", 1)) {
+            if (!e->p_rec) HIPCHK(hipMalloc(&e->p_rec, 2 * n_pad * sizeof(double4)));
+            e->P.rec = e->p_rec;
+            HIPCHK(build_source_rec(e->stream, e->P, n));
+        }
+        if (env_int("ICP_AMD_GRID_ORDER", 1)) {
+            if (!e->order) HIPCHK(hipMalloc(&e->order, n_pad * sizeof(uint32_t)));
+            HIPCHK(grid_order(e->stream, e->P, n, e->order));
+            e->order_ok = true;
+        }
+    }
+    return ICP_AMD_OK;
+}
+
 extern "C" int icp_amd_set_source(icp_amd_engine *e, const double *P, size_t n)
 {
     if (!e || (!P && n)) return fail(ICP_AMD_EINVAL, "icp_amd_set_source: NULL argument");
@@ -379,6 +412,8 @@ extern "C" int icp_amd_set_source(icp_amd_engine *e, const double *P, size_t n)
     if (n_pad != e->n_pad) {
         free_dev(e->p_store); free_dev(e->idx); free_dev(e->order);
         grid_scratch_free(&e->gscratch);
+        free_dev(e->p_rec); free_dev(e->grid_out);
+        e->p_rec = nullptr; e->grid_out = nullptr;
         e->p_store = nullptr; e->idx = nullptr; e->order = nullptr; e->n_pad = 0;
         HIPCHK(hipMalloc(&e->p_store, 3 * n_pad * sizeof(double)));
         HIPCHK(hipMalloc(&e->idx, n_pad * sizeof(uint32_t)));
@@ -415,15 +450,7 @@ extern "C" int icp_amd_set_source(icp_amd_engine *e, const double *P, size_t n)
         HIPCHK(hipMemcpyAsync(e->stage, P, n * 3 * sizeof(double), hipMemcpyHostToDevice, e->stream));
     }
     HIPCHK(aos_to_soa(e->stream, e->stage, n, n_pad, nullptr, 0.0, e->P));
-    e->order_ok = false;
-    if (n && wants_grid(e)) {
-        if (!e->gscratch.list) HIPCHK(grid_scratch_alloc(n_pad, &e->gscratch));
-        if (env_int("ICP_AMD_GRID_ORDER", 1)) {
-            if (!e->order) HIPCHK(hipMalloc(&e->order, n_pad * sizeof(uint32_t)));
-            HIPCHK(grid_order(e->stream, e->P, n, e->order));
-            e->order_ok = true;
-        }
-    }
+    RCCHK(prepare_grid_source(e));
     e->bf_left = e->bf_backoff = 0;
     HIPCHK(hipStreamSynchronize(e->stream));  // P may be reused by the caller after return
     e->have_source = true;
@@ -486,7 +513,7 @@ extern "C" int icp_amd_step_search(icp_amd_engine *e)
             RCCHK(time_begin(e, &a, &b));
         }
         const bool seed = e->have_prev && env_int("ICP_AMD_SEED", 1) != 0;
-        bool grid = e->use_grid && e->gscratch.list;
+        bool grid = e->use_grid && e->gscratch.list && e->grid_out;
         if (grid && e->grid_auto) {
             // The queue length of the most recent grid launch that has finished (a mapped host word, read without
             // waiting): when most points overflow, the tiled brute-force kernel is the faster exact search.  The grid
@@ -502,7 +529,7 @@ extern "C" int icp_amd_step_search(icp_amd_engine *e)
         if (grid) ++e->grid_launches; else ++e->bf_launches;
         if (grid)
             HIPCHK(search_grid(e->stream, e->P, e->n, e->pc, e->grid, e->Qz, e->m, seed ? e->idx : nullptr,
-                               e->order_ok ? e->order : nullptr, &e->gscratch, e->keys, e->idxs));
+                               e->order_ok ? e->order : nullptr, &e->gscratch, e->grid_out));
         else if (e->variant == kF32)
             HIPCHK(search_f32(e->stream, e->ppl, e->cb, e->P, e->n_pad, e->pc, e->Qz, e->qrec, e->qmax, e->m, e->m_pad, splits,
                               seed ? e->idx : nullptr, e->keys, e->idxs));
@@ -510,8 +537,8 @@ extern "C" int icp_amd_step_search(icp_amd_engine *e)
             HIPCHK(search(e->stream, e->variant, e->ppl, e->cb, e->P, e->n_pad, e->pc, e->Qz, e->m, e->m_pad, splits,
                           seed ? e->idx : nullptr, e->keys, e->idxs));
         if (e->opt.kernel_timing) HIPCHK(hipEventRecord(b, e->stream));
-        HIPCHK(merge_cov(e->stream, e->P, e->n, e->n_pad, e->pc, e->Qz, e->m, splits, e->keys, e->idxs, e->idx, e->reject_d2,
-                         cov_slot));
+        HIPCHK(merge_cov(e->stream, e->P, e->n, e->n_pad, e->pc, e->Qz, e->m, splits, e->keys, e->idxs, grid ? e->grid_out : nullptr,
+                         e->idx, e->reject_d2, cov_slot));
         e->have_prev = true;
     }
     return ICP_AMD_OK;
@@ -525,7 +552,7 @@ extern "C" int icp_amd_step_update(icp_amd_engine *e)
     HIPCHK(solve(e->stream, e->cov_part, e->total_chunks, e->pc, e->qc, rejecting ? -1.0 : (double)e->n_global, e->rec,
                  e->rec + kSolveW));
     double *cen_slot = e->cen_part + (size_t)e->opt.rank * e->cpr * kCenW;
-    HIPCHK(apply(e->stream, e->P, e->n, e->rec, cen_slot));
+    HIPCHK(apply(e->stream, e->P, e->n, e->rec, e->idx, cen_slot));
     return ICP_AMD_OK;
 }
 
@@ -1023,7 +1050,7 @@ extern "C" int icp_amd_correspondences(const double *P, size_t n, const double P
     RCCHK(require_device(env_int("ICP_AMD_DEVICE", 0)));
     hipStream_t s = nullptr;
     const size_t n_pad = round_up(n, kPadRows), m_pad = round_up(m, kPadRows);
-    DevBuf pst, pstage, qst, qstage, pc, keys, idxs, out, part, qrec, qmaxb;
+    DevBuf pst, pstage, qst, qstage, pc, keys, idxs, out, part, qrec, qmaxb, grec;
     Soa3 dP, dQ;
     RCCHK(upload_soa(s, P, n, n_pad, 0.0, pst, pstage, dP));
     RCCHK(upload_soa(s, Qz, m, m_pad, std::numeric_limits<double>::infinity(), qst, qstage, dQ));
@@ -1054,8 +1081,8 @@ extern "C" int icp_amd_correspondences(const double *P, size_t n, const double P
         q_splits = 1;
         struct ScratchHolder { GridScratch sc; ~ScratchHolder() { grid_scratch_free(&sc); } } sh;
         HIPCHK(grid_scratch_alloc(n, &sh.sc));
-        HIPCHK(search_grid(s, dP, n, pc.as<double>(), gh.g, dQ, m, nullptr, nullptr, &sh.sc, keys.as<double>(),
-                           idxs.as<uint32_t>()));
+        HIPCHK(grec.alloc(n_pad * sizeof(double2)));
+        HIPCHK(search_grid(s, dP, n, pc.as<double>(), gh.g, dQ, m, nullptr, nullptr, &sh.sc, grec.as<double2>()));
         HIPCHK(hipStreamSynchronize(s));   // the scratch is released on scope exit
     } else if (f32) {
         if (cb == 8) cb = 16;
@@ -1081,7 +1108,8 @@ extern "C" int icp_amd_correspondences(const double *P, size_t n, const double P
                       idxs.as<uint32_t>()));
     }
     HIPCHK(merge_cov(s, dP, n, n_pad, pc.as<double>(), dQ, m, q_splits, keys.as<double>(), idxs.as<uint32_t>(),
-                     out.as<uint32_t>(), std::numeric_limits<double>::infinity(), part.as<double>()));
+                     grid ? grec.as<double2>() : nullptr, out.as<uint32_t>(), std::numeric_limits<double>::infinity(),
+                     part.as<double>()));
     HIPCHK(hipMemcpyAsync(idx, out.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     return ICP_AMD_OK;
@@ -1176,7 +1204,7 @@ extern "C" int icp_amd_apply(const double *P, size_t n, const double R[9], const
     HIPCHK(rec.alloc(sizeof h));
     HIPCHK(cen.alloc((n_pad / kChunk) * kCenW * sizeof(double)));
     HIPCHK(hipMemcpyAsync(rec.p, h, sizeof h, hipMemcpyHostToDevice, s));
-    HIPCHK(apply(s, dP, n, rec.as<double>(), cen.as<double>()));
+    HIPCHK(apply(s, dP, n, rec.as<double>(), nullptr, cen.as<double>()));
     HIPCHK(soa_to_aos(s, dP, n, pstage.as<double>()));
     HIPCHK(hipMemcpyAsync(P_out, pstage.p, n * 3 * sizeof(double), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));

@@ -221,32 +221,40 @@ __global__ __launch_bounds__(kWG) void search_grid_kernel(const double *__restri
                                                           const double *__restrict__ qz, const double4 *__restrict__ qrec4,
                                                           unsigned m,
                                                           const uint32_t *__restrict__ idx_prev,
-                                                          const uint32_t *__restrict__ order, int row_cap, unsigned eval_cap,
-                                                          uint32_t *__restrict__ ovf_count, uint32_t *__restrict__ ovf_list,
-                                                          double *__restrict__ out_key, uint32_t *__restrict__ out_idx)
+                                                          const double4 *__restrict__ prec, const uint32_t *__restrict__ order,
+                                                          int row_cap, unsigned eval_cap, uint32_t *__restrict__ ovf_count,
+                                                          uint32_t *__restrict__ ovf_list, double2 *__restrict__ out_rec)
 {
     const size_t l = (size_t)blockIdx.x * kWG + threadIdx.x;
     if (l >= n) return;
-    // order: source rows sorted by position, so that the lanes of a wave walk the same few cells (cache lines shared)
+    // order: source rows sorted by position, so that the lanes of a wave walk the same few cells (cache lines shared).
+    // The rows themselves stay where they are, so everything a lane needs of its row comes from one 64-byte record
+    // when the caller keeps one (prec: {x, y, z, previous index}, {that target's coordinates}).
     const size_t i = order ? order[l] : l;
-    const double ax = px[i] - pc[0], ay = py[i] - pc[1], az = pz[i] - pc[2];
+    double ax, ay, az, sqx = 0.0, sqy = 0.0, sqz = 0.0;
+    uint32_t js = 0xFFFFFFFFu;
+    if (prec) {
+        const double4 v0 = prec[2 * i], v1 = prec[2 * i + 1];
+        ax = v0.x - pc[0]; ay = v0.y - pc[1]; az = v0.z - pc[2];
+        if (idx_prev) js = (uint32_t)__double_as_longlong(v0.w);
+        sqx = v1.x; sqy = v1.y; sqz = v1.z;
+    } else {
+        ax = px[i] - pc[0]; ay = py[i] - pc[1]; az = pz[i] - pc[2];
+        if (idx_prev) js = idx_prev[i];
+    }
     double bk = INFINITY, dmin = INFINITY;   // oracle: min_dist = DBL_MAX on the key, idx = -1
     uint32_t bj = 0xFFFFFFFFu;
     const double amax = __builtin_fmax(__builtin_fmax(__builtin_fabs(ax), __builtin_fabs(ay)), __builtin_fabs(az));
     if (!(amax < INFINITY) || ax != ax || ay != ay || az != az) {   // every d^2 is inf or NaN: no correspondence
-        out_key[i] = bk;
-        out_idx[i] = bj;
+        out_rec[i] = make_double2(bk, __longlong_as_double((long long)bj));
         return;
     }
-    if (idx_prev) {
-        const uint32_t js = idx_prev[i];
-        if (js < m) {
-            const double d = seed_d2(ax, ay, az, js, qx, qy, qz, qrec4);
-            if (d < INFINITY) {
-                dmin = d;
-                bk = key_of(d);
-                bj = js;
-            }
+    if (js < m) {
+        const double d = prec ? d2_exact(ax, ay, az, sqx, sqy, sqz) : seed_d2(ax, ay, az, js, qx, qy, qz, qrec4);
+        if (d < INFINITY) {
+            dmin = d;
+            bk = key_of(d);
+            bj = js;
         }
     }
     double edge = dmin < INFINITY ? tie_band(dmin) : INFINITY;
@@ -275,8 +283,7 @@ __global__ __launch_bounds__(kWG) void search_grid_kernel(const double *__restri
         if (defer || b.all || b.B > edge) break;
         r = next_radius(edge, r);
     }
-    out_key[i] = bk;   // deferred: the best found so far, the overflow kernel starts from it
-    out_idx[i] = bj;
+    out_rec[i] = make_double2(bk, __longlong_as_double((long long)bj));   // deferred: the best so far, the overflow kernel starts from it
     if (defer) ovf_list[atomicAdd(ovf_count, 1u)] = (uint32_t)i;
 }
 
@@ -290,7 +297,7 @@ __global__ __launch_bounds__(kWG) void search_grid_overflow_kernel(
     const double *__restrict__ qy, const double *__restrict__ qz, const double4 *__restrict__ qrec4, unsigned m,
     const uint32_t *__restrict__ ovf_count,
     uint32_t *__restrict__ ovf_count_next, const uint32_t *__restrict__ ovf_list, uint32_t *__restrict__ host_count,
-    double *__restrict__ out_key, uint32_t *__restrict__ out_idx)
+    double2 *__restrict__ out_rec)
 {
     __shared__ double s_d[kWG / 64], s_k[kWG / 64];
     __shared__ uint32_t s_j[kWG / 64];
@@ -306,7 +313,7 @@ __global__ __launch_bounds__(kWG) void search_grid_overflow_kernel(
         const double amax = __builtin_fmax(__builtin_fmax(__builtin_fabs(ax), __builtin_fabs(ay)), __builtin_fabs(az));
         double bk = INFINITY, dmin = INFINITY;
         uint32_t bj = 0xFFFFFFFFu;
-        const uint32_t js = out_idx[i];
+        const uint32_t js = (uint32_t)__double_as_longlong(out_rec[i].y);
         if (js < m) {
             const double d = seed_d2(ax, ay, az, js, qx, qy, qz, qrec4);
             if (d < INFINITY) {
@@ -346,10 +353,7 @@ __global__ __launch_bounds__(kWG) void search_grid_overflow_kernel(
             if (b.all || b.B > edge) break;
             r = next_radius(edge, r);
         }
-        if (threadIdx.x == 0) {
-            out_key[i] = bk;
-            out_idx[i] = bj;
-        }
+        if (threadIdx.x == 0) out_rec[i] = make_double2(bk, __longlong_as_double((long long)bj));
     }
 }
 
@@ -510,7 +514,7 @@ hipError_t grid_order(hipStream_t s, Soa3 P, size_t n, uint32_t *order)
 }
 
 hipError_t search_grid(hipStream_t s, Soa3 P, size_t n, const double *pc, const Grid &g, Soa3 Qz, size_t m,
-                       const uint32_t *idx_prev, const uint32_t *order, GridScratch *sc, double *out_key, uint32_t *out_idx)
+                       const uint32_t *idx_prev, const uint32_t *order, GridScratch *sc, double2 *out_rec)
 {
     if (!g.ok || m == 0 || m > 0xFFFFFFF0u) return hipErrorInvalidValue;
     if (n == 0) return hipSuccess;
@@ -518,14 +522,13 @@ hipError_t search_grid(hipStream_t s, Soa3 P, size_t n, const double *pc, const 
     const int eval_cap = getenv("ICP_AMD_GRID_EVALCAP") ? atoi(getenv("ICP_AMD_GRID_EVALCAP")) : 768;
     uint32_t *cnt = sc ? sc->count2 + sc->parity : nullptr, *cnt_next = sc ? sc->count2 + (sc->parity ^ 1) : nullptr;
     search_grid_kernel<<<(unsigned)((n + kWG - 1) / kWG), kWG, 0, s>>>(P.x, P.y, P.z, pc, n, g.d, g.start, g.rec, Qz.x, Qz.y, Qz.z,
-                                                                      Qz.rec, (unsigned)m, idx_prev, order, row_cap,
-                                                                      (unsigned)eval_cap, cnt, sc ? sc->list : nullptr, out_key,
-                                                                      out_idx);
+                                                                      Qz.rec, (unsigned)m, idx_prev, P.rec, order, row_cap,
+                                                                      (unsigned)eval_cap, cnt, sc ? sc->list : nullptr, out_rec);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || !sc) return e;
     size_t wgs = n < 2048 ? n : 2048;
     search_grid_overflow_kernel<<<(unsigned)wgs, kWG, 0, s>>>(P.x, P.y, P.z, pc, g.d, g.start, g.rec, Qz.x, Qz.y, Qz.z, Qz.rec,
-                                                             (unsigned)m, cnt, cnt_next, sc->list, sc->host_count, out_key, out_idx);
+                                                             (unsigned)m, cnt, cnt_next, sc->list, sc->host_count, out_rec);
     sc->parity ^= 1;
     return hipGetLastError();
 }

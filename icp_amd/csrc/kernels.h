@@ -91,15 +91,22 @@ hipError_t grid_scratch_alloc(size_t n, GridScratch *sc);
 void grid_scratch_free(GridScratch *sc);
 // order: optional processing order of the source rows (grid_order), a permutation of [0, n); results do not depend on it.
 // sc == nullptr: every lane finishes its own point, however large its box.
+// out_rec: one {key, idx as an integer bit pattern} record per source row i < n (merge_cov's grid_rec).
+// P.rec, when set, holds TWO records per source row: {x, y, z, previous idx (bit pattern)} and {coordinates of that
+// target, unused} -- everything a lane needs of its row in one 64-byte line (kept current by apply and merge_cov).
 hipError_t search_grid(hipStream_t s, Soa3 P, size_t n, const double *pc, const Grid &g, Soa3 Qz, size_t m,
-                       const uint32_t *idx_prev, const uint32_t *order, GridScratch *sc, double *out_key, uint32_t *out_idx);
+                       const uint32_t *idx_prev, const uint32_t *order, GridScratch *sc, double2 *out_rec);
+// P.rec[2i] = {x, y, z, "no index"}, P.rec[2i+1] = 0 for i < rows
+hipError_t build_source_rec(hipStream_t s, Soa3 P, size_t rows);
 hipError_t grid_order(hipStream_t s, Soa3 P, size_t n, uint32_t *order);
 
 // Merge the splits (lowest index among equal keys), write idx[n], and reduce q (x) p per 1024-row chunk
 // into partial[chunk][12].
 hipError_t merge_cov(hipStream_t s, Soa3 P, size_t n, size_t n_pad, const double *pc, Soa3 Qz, size_t m,
-                     int q_splits, const double *keys, const uint32_t *idxs, uint32_t *idx_out, double reject_d2,
-                     double *partial);
+                     int q_splits, const double *keys, const uint32_t *idxs, const double2 *grid_rec, uint32_t *idx_out,
+                     double reject_d2, double *partial);
+// grid_rec != nullptr: the (key, idx) records of search_grid instead of keys / idxs (q_splits is then 1).
+// P.rec != nullptr: the matched target's coordinates are stored in P.rec[2i+1] (next iteration's seed).
 // reject_d2: pairs farther apart than this (squared, the oracle's un-fused d^2) get weight 0 in the sums; +inf = none.
 // partial slots: [0..8] cov, [9] sum of d^2, [10] number of pairs that entered the sums, [11] spare.
 // cov partials from a given idx (stage-level entry).
@@ -114,7 +121,8 @@ constexpr int kSolveW = 28;
 hipError_t solve(hipStream_t s, const double *partial, size_t count, const double *pc, const double *qc,
                  double n_global, double *out, double *extra);
 // P <- P R^T + t (R, t read from the solve record) and per-chunk sums of the new P.
-hipError_t apply(hipStream_t s, Soa3 P, size_t n, const double *solve_rec, double *cen_partial);
+// P.rec != nullptr: also P.rec[2i] = {new x, y, z, idx[i]}.
+hipError_t apply(hipStream_t s, Soa3 P, size_t n, const double *solve_rec, const uint32_t *idx, double *cen_partial);
 
 // Multi-registration mode: `batch` independent registrations of n x m points, one workgroup each, all iterations
 // on-chip.  P_in [batch][n][3], Q_in [batch][m][3] row-major; P_out same shape; rec_out [batch][kSolveW] = the

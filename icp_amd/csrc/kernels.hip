@@ -530,9 +530,9 @@ __global__ __launch_bounds__(kWG) void cov_kernel(const double *__restrict__ px,
                                                   const double *__restrict__ qy, const double *__restrict__ qz,
                                                   const double4 *__restrict__ qrec4, size_t m,
                                                   int q_splits, const double *__restrict__ keys,
-                                                  const uint32_t *__restrict__ idxs, const uint32_t *__restrict__ idx_in,
-                                                  uint32_t *__restrict__ idx_out, double reject_d2,
-                                                  double *__restrict__ partial)
+                                                  const uint32_t *__restrict__ idxs, const double2 *__restrict__ grid_rec,
+                                                  const uint32_t *__restrict__ idx_in, uint32_t *__restrict__ idx_out,
+                                                  double4 *__restrict__ prec, double reject_d2, double *__restrict__ partial)
 {
     __shared__ double smem[4 * kCovW];
     const double c0 = pc[0], c1 = pc[1], c2 = pc[2];
@@ -545,7 +545,10 @@ __global__ __launch_bounds__(kWG) void cov_kernel(const double *__restrict__ px,
         const size_t i = base + (size_t)k * kWG;
         if (i < n) {
             uint32_t j;
-            if (MERGE) {
+            if (MERGE && grid_rec) {
+                j = (uint32_t)__double_as_longlong(grid_rec[i].y);
+                idx_out[i] = j;
+            } else if (MERGE) {
                 double bk = keys[i];
                 j = idxs[i];
                 for (int y = 1; y < q_splits; ++y) {  // lexicographic (key, index): a split may report the seed
@@ -571,6 +574,7 @@ __global__ __launch_bounds__(kWG) void cov_kernel(const double *__restrict__ px,
                 }
                 // the weight hook of compute_cross_variance (src/cpu/icp.cpp:108-131: weight = kernel(p - q), a constant 1
                 // there) as a hard threshold on the pair's distance: weight 1 up to reject_d2 (+inf = the reference), else 0
+                if (MERGE && prec) prec[2 * i + 1] = make_double4(q0, q1, q2, 0.0);   // the next search's seed, next to its point
                 const double d = d2_exact(p0, p1, p2, q0, q1, q2);
                 if (d <= reject_d2) {
                     acc[0] += q0 * p0; acc[1] += q0 * p1; acc[2] += q0 * p2;
@@ -737,7 +741,8 @@ __device__ void solve_record(const double *tot, const double *pc, const double *
 // P_copy = P_copy.dot(R.transpose()) + t (src/cpu/icp.cpp:225): per row and output column j,
 // ((0 + x R[j][0]) + y R[j][1]) + z R[j][2], then + t[j]; un-fused.
 __global__ __launch_bounds__(kWG) void apply_kernel(double *__restrict__ px, double *__restrict__ py, double *__restrict__ pz,
-                                                    size_t n, const double *__restrict__ rec, double *__restrict__ cen_partial)
+                                                    size_t n, const double *__restrict__ rec, const uint32_t *__restrict__ idx,
+                                                    double4 *__restrict__ prec, double *__restrict__ cen_partial)
 {
     __shared__ double smem[4 * 3];
     const double *R = rec + 12, *t = rec + 21;
@@ -756,6 +761,7 @@ __global__ __launch_bounds__(kWG) void apply_kernel(double *__restrict__ px, dou
             px[i] = nx;
             py[i] = ny;
             pz[i] = nz;
+            if (prec) prec[2 * i] = make_double4(nx, ny, nz, __longlong_as_double((long long)idx[i]));
             acc[0] += nx;
             acc[1] += ny;
             acc[2] += nz;
@@ -1048,6 +1054,22 @@ hipError_t build_rec(hipStream_t s, Soa3 soa, size_t rows)
     return hipGetLastError();
 }
 
+__global__ __launch_bounds__(kWG) void build_source_rec_kernel(const double *__restrict__ x, const double *__restrict__ y,
+                                                               const double *__restrict__ z, size_t rows, double4 *__restrict__ rec)
+{
+    const size_t i = (size_t)blockIdx.x * kWG + threadIdx.x;
+    if (i >= rows) return;
+    rec[2 * i] = make_double4(x[i], y[i], z[i], __longlong_as_double(0xFFFFFFFFll));
+    rec[2 * i + 1] = make_double4(0.0, 0.0, 0.0, 0.0);
+}
+
+hipError_t build_source_rec(hipStream_t s, Soa3 P, size_t rows)
+{
+    if (rows == 0 || !P.rec) return hipErrorInvalidValue;
+    build_source_rec_kernel<<<blocks_for(rows, kWG), kWG, 0, s>>>(P.x, P.y, P.z, rows, P.rec);
+    return hipGetLastError();
+}
+
 hipError_t soa_to_aos(hipStream_t s, Soa3 in, size_t n, double *aos)
 {
     if (n == 0) return hipSuccess;
@@ -1130,11 +1152,12 @@ hipError_t search_f32(hipStream_t s, int ppl, int cb, Soa3 P, size_t n_pad, cons
 }
 
 hipError_t merge_cov(hipStream_t s, Soa3 P, size_t n, size_t n_pad, const double *pc, Soa3 Qz, size_t m, int q_splits,
-                     const double *keys, const uint32_t *idxs, uint32_t *idx_out, double reject_d2, double *partial)
+                     const double *keys, const uint32_t *idxs, const double2 *grid_rec, uint32_t *idx_out, double reject_d2,
+                     double *partial)
 {
     if (n == 0) return hipSuccess;
     cov_kernel<true><<<blocks_for(n, kChunk), kWG, 0, s>>>(P.x, P.y, P.z, n, n_pad, pc, Qz.x, Qz.y, Qz.z, Qz.rec, m, q_splits, keys,
-                                                           idxs, nullptr, idx_out, reject_d2, partial);
+                                                           idxs, grid_rec, nullptr, idx_out, P.rec, reject_d2, partial);
     return hipGetLastError();
 }
 
@@ -1143,7 +1166,7 @@ hipError_t cov_from_idx(hipStream_t s, Soa3 P, size_t n, const double *pc, Soa3 
 {
     if (n == 0) return hipSuccess;
     cov_kernel<false><<<blocks_for(n, kChunk), kWG, 0, s>>>(P.x, P.y, P.z, n, 0, pc, Qz.x, Qz.y, Qz.z, Qz.rec, m, 1, nullptr, nullptr,
-                                                            idx, nullptr, INFINITY, partial);
+                                                            nullptr, idx, nullptr, nullptr, INFINITY, partial);
     return hipGetLastError();
 }
 
@@ -1154,10 +1177,11 @@ hipError_t solve(hipStream_t s, const double *partial, size_t count, const doubl
     return hipGetLastError();
 }
 
-hipError_t apply(hipStream_t s, Soa3 P, size_t n, const double *solve_rec, double *cen_partial)
+hipError_t apply(hipStream_t s, Soa3 P, size_t n, const double *solve_rec, const uint32_t *idx, double *cen_partial)
 {
     if (n == 0) return hipSuccess;
-    apply_kernel<<<blocks_for(n, kChunk), kWG, 0, s>>>(P.x, P.y, P.z, n, solve_rec, cen_partial);
+    if (P.rec && !idx) return hipErrorInvalidValue;
+    apply_kernel<<<blocks_for(n, kChunk), kWG, 0, s>>>(P.x, P.y, P.z, n, solve_rec, idx, P.rec, cen_partial);
     return hipGetLastError();
 }
 

@@ -187,3 +187,36 @@ def test_grid_overflow_queue_and_auto_fallback(monkeypatch):
         assert np.array_equal(outs[0][0], o[0]) and np.array_equal(outs[0][1], o[1])
     assert stats["f32"]["grid_launches"] == 0 and stats["grid"]["brute_force_launches"] == 0
     assert stats["auto"]["grid_launches"] >= 1 and stats["auto"]["brute_force_launches"] >= 1, stats
+
+
+def test_grid_state_follows_target_and_source_replacement():
+    """AUTO decides per target: a small target (brute force) replaced by a large one under the same source switches to
+    the grid, and back; a new source under the same target rebuilds the per-source records.  Results = brute force."""
+    P, Qs = synth.make_pair(5000, 1500, seed=41)
+    _, Ql = synth.make_pair(5000, 9000, seed=42)
+    e = icp_amd.Engine()
+    e.set_target(Qs)
+    e.set_source(P)
+    assert e.search_geometry()["variant"] == "f32"
+    e.iterate(2)
+    e.set_target(Ql)
+    assert e.search_geometry()["variant"] == "grid"
+    P_mid = e.get_source()
+    e.iterate(3)
+    got = (e.get_last()["idx"], e.get_source())
+    assert e.grid_stats()["grid_launches"] == 3
+    e.set_target(Qs)
+    assert e.search_geometry()["variant"] == "f32"
+    e.set_target(Ql)
+    e.set_source(P_mid)
+    e.iterate(3)
+    again = (e.get_last()["idx"], e.get_source())
+    e.close()
+    b = icp_amd.Engine(search="exact")
+    b.set_target(Ql)
+    b.set_source(P_mid)
+    b.iterate(3)
+    want = (b.get_last()["idx"], b.get_source())
+    b.close()
+    for r in (got, again):
+        assert np.array_equal(r[0], want[0]) and np.array_equal(r[1], want[1])
