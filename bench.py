@@ -26,6 +26,18 @@ PEAK_FP32_VALU = 157.3e12        # MI355X fp32 vector peak (MI355X_MICROARCH.md;
 FLOPS_PER_PAIR = 8               # 3 sub, 3 mul, 2 add: the oracle's un-fused distance
 
 
+def measured_traffic(kernel, n, m, world):
+    """Bytes per launch from the committed PMC passes (icp_amd/measured_traffic.json), or None when they were taken on
+    another workload: bench.py cannot collect counters itself (rocprofv3 runs them as separate passes)."""
+    try:
+        rec = json.load(open(os.path.join(ROOT, "icp_amd", "measured_traffic.json"))).get(kernel)
+    except (OSError, ValueError):
+        return None
+    if rec and rec["n"] == n and rec["m"] == m and rec["n_gpus"] == world:
+        return rec["traffic_bytes"]
+    return None
+
+
 def roofline(variant, n_local, M, avg_ms, launches):
     """Roofline object of the search kernel.  `achieved` is ALGORITHMIC: 8 flops per (p,q) pair x the
     pairs of one launch / the kernel's hipEvent-timed average launch duration, whatever instruction mix the variant's
@@ -87,6 +99,40 @@ def cpu_baseline(P, Q, seconds_target=30.0):
             "sample": "correspondence search of the first %d source rows x %d targets, %d OpenMP threads, %.1f s"
                       % (rows, m, cores, dt),
             "iters_per_sec_extrapolated": (rows * m / dt) / (len(P) * float(m))}
+
+
+def cpu_reference(P, Q, rows=4000, targets=20000):
+    """The UNMODIFIED reference CPU code (oracle/_ref/ref_trace: the reference's own get_correspondence_indices,
+    src/cpu/icp.cpp:72-93, compiled from its sources where they lie) timed on a bounded sample of the same clouds.
+    Single-threaded, like CPUICP.  The CSV parse is taken out by subtracting a run with one source row."""
+    import subprocess
+    import tempfile
+    exe = os.path.join(ROOT, "oracle", "_ref", "ref_trace")
+    if not os.path.exists(exe):
+        return None
+    from oracle import pyoracle as orc
+    Pz = (P - orc.mean0(P))[:rows]
+    Qz = (Q - orc.mean0(Q))[:targets]
+    try:
+        with tempfile.TemporaryDirectory() as d:
+            def dump(name, A):
+                path = os.path.join(d, name)
+                np.savetxt(path, A, fmt="%.17g", delimiter=",", header="Points_0,Points_1,Points_2", comments="")
+                return path
+            pf, p1, qf, out = dump("p.csv", Pz), dump("p1.csv", Pz[:1]), dump("q.csv", Qz), os.path.join(d, "o.bin")
+            times = []
+            for src in (p1, pf):
+                t0 = time.perf_counter()
+                subprocess.run([exe, "--corr", src, qf, out], check=True, capture_output=True, timeout=300)
+                times.append(time.perf_counter() - t0)
+            idx = np.fromfile(out, dtype=np.int32)
+        dt = max(times[1] - times[0], 1e-6)
+        ok = bool(np.array_equal(idx[-len(Pz):], orc.correspondences(Pz, Qz, nthreads=4))) if len(idx) >= len(Pz) else None
+        return {"value": (len(Pz) - 1) * float(len(Qz)) / dt, "unit": "distance evals/s", "cores": 1, "kind": "reference",
+                "sample": "reference get_correspondence_indices on the first %d source rows x first %d targets of the same "
+                          "clouds, %.1f s" % (len(Pz), len(Qz), dt), "indices_equal_oracle": ok}
+    except Exception as exc:   # the baseline is a report, never a reason for the bench to fail
+        return {"error": repr(exc)[:200], "kind": "reference"}
 
 
 def bench_batch(args, rank, world, local_rank):
@@ -257,6 +303,11 @@ def main():
             "roofline": roofline(geo["variant"], n_local, M, search_avg_ms, launches),
             "rms_last": last["rms"],
         }
+        if geo["variant"] == "f32":
+            out["roofline"]["traffic"] = measured_traffic("search_f32_kernel", N, M, world)
+            out["roofline"]["traffic_note"] = ("bytes per launch at the L2's memory side (FETCH_SIZE x 2 + WRITE_SIZE, separate "
+                                               "rocprofv3 --pmc passes, profiles/r1_v5_pmc_*.txt); includes Infinity-Cache hits; "
+                                               "the kernel is VALU bound: this is 0.14 TB/s")
         if grid:
             out["grid_search"] = grid
         if world == 1 and not args.no_fp64_variants:
@@ -264,6 +315,9 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(P, Q)
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+            ref = cpu_reference(P, Q)
+            if ref:
+                out["cpu_reference"] = ref
         print(json.dumps(out), flush=True)
     if world > 1:
         td.barrier()

@@ -704,9 +704,10 @@ extern "C" int icp_amd_kernel_ms(icp_amd_engine *e, double *avg_ms, double *tota
 extern "C" int icp_amd_search_geometry(icp_amd_engine *e, int *ppl, int *q_splits, int *workgroups, int *variant)
 {
     if (!e || !e->have_source) return fail(ICP_AMD_ESTATE, "icp_amd_search_geometry: no source cloud");
-    if (ppl) *ppl = e->ppl;
-    if (q_splits) *q_splits = e->q_splits;
-    if (workgroups) *workgroups = (int)(e->n_pad / ((size_t)kWG * e->ppl)) * e->q_splits;
+    if (ppl) *ppl = e->use_grid ? 1 : e->ppl;
+    if (q_splits) *q_splits = e->use_grid ? 1 : e->q_splits;
+    if (workgroups)
+        *workgroups = e->use_grid ? (int)((e->n + kWG - 1) / kWG) : (int)(e->n_pad / ((size_t)kWG * e->ppl)) * e->q_splits;
     if (variant) *variant = e->use_grid ? (int)kGrid : e->variant;
     return ICP_AMD_OK;
 }

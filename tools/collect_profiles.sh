@@ -21,4 +21,9 @@ python3 $R/tools/rocprof_summary.py --pmc $O/pmc_fetch/p_results.db > $O/pmc_fet
 timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE -d $O/pmc_write -o p -- python3 $R/bench.py --steps 2 --warmup 1 $SHORT > /dev/null 2> $O/pmc_write.err
 python3 $R/tools/rocprof_summary.py --pmc $O/pmc_write/p_results.db > $O/pmc_write.txt
 echo "pmc tcc done" >> $O/progress.txt
+timeout -k 10 300 python3 -u $R/tools/grid_probe.py > $O/grid_probe.txt 2>&1
+timeout -k 10 300 python3 -u $R/tools/small_probe.py > $O/small_probe.txt 2>&1
+ICP_AMD_SEARCH=f32 timeout -k 10 300 python3 -u $R/tools/small_probe.py > $O/small_probe_f32.txt 2>&1
+timeout -k 10 200 python3 $R/bench.py --workload batch --steps 5 --warmup 2 > $O/bench_batch.json 2> $O/bench_batch.err
+echo "probes done" >> $O/progress.txt
 rm -rf $O/trace $O/pmc_sq $O/pmc_fetch $O/pmc_write
