@@ -959,7 +959,8 @@ extern "C" int icp_amd_batch_run(icp_amd_batch *b, unsigned iters, int search_va
     if (!b) return fail(ICP_AMD_EINVAL, "icp_amd_batch_run: NULL handle");
     if (!b->uploaded) return fail(ICP_AMD_ESTATE, "icp_amd_batch_run: upload the clouds first");
     HIPCHK(hipSetDevice(b->device));
-    int variant = search_variant == ICP_AMD_SEARCH_EXACT ? kExact : kFma;
+    // EXACT / FMA: the difference form on SoA targets; anything else (AUTO, F32, GRID): the expanded form on records
+    int variant = search_variant == ICP_AMD_SEARCH_EXACT ? kExact : search_variant == ICP_AMD_SEARCH_FMA ? kFma : kExpanded;
     const char *sv = getenv("ICP_AMD_SEARCH");
     if (sv && !strcmp(sv, "fma")) variant = kFma;
     if (sv && !strcmp(sv, "exact")) variant = kExact;

@@ -859,6 +859,76 @@ __device__ __forceinline__ void scan_small(const double (&ax)[PPL], const double
     }
 }
 
+// --- expanded form (batch default): the fast path works on s_j = |q_j|^2 - 2 p.q_j (= d^2 - |p|^2, same argmin) with the
+// target as one 32-byte LDS record {-2qx, -2qy, -2qz, |q|^2}: three v_fma_f64 instead of three subtractions, a multiply
+// and two FMAs -- 7 instructions per pair with the index embedding and the runner-up tracking instead of 10.
+// |s_j(computed) - s_j| <= E = 2^-52 (11 |p| |q|max + 5 |q|max^2) (the bound of search_f32_kernel with fp64's epsilon),
+// so if the runner-up is more than 2E + 2^-38 (|s| + |p|^2) above the minimum (index truncation 2^-40 |s| on both, tie
+// band 2^-48 d^2) no other target can reach the winner's key; otherwise the point is re-scanned exactly.
+constexpr double kExpPadW = 1e300;   // pad record: s = 1e300, finite
+
+__device__ __forceinline__ double embed_index(double v, unsigned j)
+{
+    unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    unsigned lo;
+    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(lo) : "v"((unsigned)b), "s"(kSmallIdxMask), "v"(j));
+    b = (b & 0xFFFFFFFF00000000ull) | lo;
+    return __longlong_as_double((long long)b);
+}
+
+// Exact (oracle-order) scan from the records: q = -X/2 exactly (a power-of-two scaling).
+__device__ __noinline__ uint32_t exact_scan_small_rec(double ax, double ay, double az, const double4 *rec, unsigned m)
+{
+    double bd = INFINITY, bk = INFINITY;
+    uint32_t bj = 0xFFFFFFFFu;
+    for (unsigned j = 0; j < m; ++j) {
+        const double4 v = rec[j];
+        const double d = d2_exact(ax, ay, az, -0.5 * v.x, -0.5 * v.y, -0.5 * v.z);
+        if (d < bd) {
+            bd = d;
+            const double key = key_of(d);
+            if (key < bk) {
+                bk = key;
+                bj = j;
+            }
+        }
+    }
+    return bj;
+}
+
+template <int PPL>
+__device__ __forceinline__ void scan_small_expanded(const double (&ax)[PPL], const double (&ay)[PPL], const double (&az)[PPL],
+                                                    const double4 *rec, unsigned m, unsigned m_pad, double qmax2, uint32_t (&bj)[PPL])
+{
+    double m1[PPL], m2[PPL];
+#pragma unroll
+    for (int s = 0; s < PPL; ++s) m1[s] = m2[s] = INFINITY;
+    for (unsigned j0 = 0; j0 < m_pad; j0 += 4) {
+#pragma unroll
+        for (unsigned u = 0; u < 4; ++u) {
+            const double4 v = rec[j0 + u];
+#pragma unroll
+            for (int s = 0; s < PPL; ++s) {
+                const double t = embed_index(__builtin_fma(az[s], v.z, __builtin_fma(ay[s], v.y, __builtin_fma(ax[s], v.x, v.w))), j0 + u);
+                m2[s] = vmin64(m2[s], vmax64(m1[s], t));
+                m1[s] = vmin64(m1[s], t);
+            }
+        }
+    }
+    const bool range_ok = qmax2 < 1e280;   // false also for NaN
+    const double qmax = sqrt(qmax2);
+#pragma unroll
+    for (int s = 0; s < PPL; ++s) {
+        const unsigned j = (unsigned)__double_as_longlong(m1[s]) & ~kSmallIdxMask;
+        const double pn = (ax[s] * ax[s] + ay[s] * ay[s]) + az[s] * az[s];
+        const double E = 0x1p-52 * (11.0 * sqrt(pn) * qmax + 5.0 * qmax2);
+        const double tol = 2.0 * E + 0x1p-38 * (__builtin_fabs(m1[s]) + pn) + 1e-300;
+        const bool unique = range_ok && pn < 1e280 && (m2[s] - m1[s] > tol) && __builtin_fabs(m1[s]) < 1e290 && j < m;
+        bj[s] = j;
+        if (!unique) bj[s] = exact_scan_small_rec(ax[s], ay[s], az[s], rec, m);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // multi-registration mode: one workgroup = one whole registration, every iteration on-chip
 // ------------------------------------------------------------------------------------------------
@@ -873,8 +943,10 @@ __global__ __launch_bounds__(kWG) void batch_icp_kernel(const double *__restrict
                                                         double *__restrict__ rec_out, uint32_t *__restrict__ idx_out)
 {
     extern __shared__ double lds[];
+    constexpr bool EXP = MODE == kExpanded;   // targets as {-2q, |q|^2} records (4 doubles) instead of SoA (3 doubles)
     double *sx = lds, *sy = lds + m_pad, *sz = lds + 2 * (size_t)m_pad;
-    double *red = lds + 3 * (size_t)m_pad;  // 4*12: scratch of block_sum
+    double4 *trec = (double4 *)lds;
+    double *red = lds + (EXP ? 4 : 3) * (size_t)m_pad;  // 4*12: scratch of block_sum
     double *bc = red + 48;                  // [0..2] Pc, [4..15] cov sums, [16..18] Qc, [20..47] solve record
     constexpr int NCH = PPL / 4;            // 1024-row chunks covered by the PPL*256 slots
     const unsigned tid = threadIdx.x;
@@ -901,11 +973,38 @@ __global__ __launch_bounds__(kWG) void batch_icp_kernel(const double *__restrict
     if (tid < 3) bc[16 + tid] = tq / (double)m;
     __syncthreads();
     const double qc0 = bc[16], qc1 = bc[17], qc2 = bc[18];
+    double qn_max = 0.0;
     for (unsigned j = tid; j < m_pad; j += kWG) {
         const bool in = j < m;
-        sx[j] = in ? Qb[(size_t)j * 3 + 0] - qc0 : kSmallPad;
-        sy[j] = in ? Qb[(size_t)j * 3 + 1] - qc1 : kSmallPad;
-        sz[j] = in ? Qb[(size_t)j * 3 + 2] - qc2 : kSmallPad;
+        if constexpr (EXP) {
+            double4 r = make_double4(0.0, 0.0, 0.0, kExpPadW);
+            if (in) {
+                const double x = Qb[(size_t)j * 3 + 0] - qc0, y = Qb[(size_t)j * 3 + 1] - qc1, z = Qb[(size_t)j * 3 + 2] - qc2;
+                const double w = (x * x + y * y) + z * z;
+                r = make_double4(-2.0 * x, -2.0 * y, -2.0 * z, w);
+                qn_max = (w > qn_max || w != w) ? w : qn_max;   // a NaN sticks: the range test then fails
+            }
+            trec[j] = r;
+        } else {
+            sx[j] = in ? Qb[(size_t)j * 3 + 0] - qc0 : kSmallPad;
+            sy[j] = in ? Qb[(size_t)j * 3 + 1] - qc1 : kSmallPad;
+            sz[j] = in ? Qb[(size_t)j * 3 + 2] - qc2 : kSmallPad;
+        }
+    }
+    if constexpr (EXP) {   // max |q|^2 of this registration's centred target -> bc[3]
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            const double other = __shfl_xor(qn_max, o, 64);
+            qn_max = (other > qn_max || other != other) ? other : qn_max;
+        }
+        __syncthreads();   // red is free again (block_sum above)
+        if ((tid & 63) == 0) red[tid >> 6] = qn_max;
+        __syncthreads();
+        if (tid == 0) {
+            double v = red[0];
+            for (int w = 1; w < kWG / 64; ++w) v = (red[w] > v || red[w] != red[w]) ? red[w] : v;
+            bc[3] = v;
+        }
     }
     double px[PPL], py[PPL], pz[PPL];
     uint32_t bj[PPL];
@@ -951,7 +1050,10 @@ __global__ __launch_bounds__(kWG) void batch_icp_kernel(const double *__restrict
             ay[s] = py[s] - c1;
             az[s] = pz[s] - c2;
         }
-        scan_small<PPL, MODE>(ax, ay, az, sx, sy, sz, m, m_pad, bj);
+        if constexpr (EXP)
+            scan_small_expanded<PPL>(ax, ay, az, trec, m, m_pad, bc[3], bj);
+        else
+            scan_small<PPL, MODE>(ax, ay, az, sx, sy, sz, m, m_pad, bj);
 
         // cross-covariance (src/cpu/icp.cpp:214)
         double tv = 0.0;
@@ -966,7 +1068,13 @@ __global__ __launch_bounds__(kWG) void batch_icp_kernel(const double *__restrict
                 const uint32_t j = bj[s];
                 if (s * kWG + tid < n && j < m) {
                     const double p0 = ax[s], p1 = ay[s], p2 = az[s];
-                    const double q0 = sx[j], q1 = sy[j], q2 = sz[j];
+                    double q0, q1, q2;
+                    if constexpr (EXP) {
+                        const double4 v = trec[j];
+                        q0 = -0.5 * v.x; q1 = -0.5 * v.y; q2 = -0.5 * v.z;   // exact: power-of-two scaling
+                    } else {
+                        q0 = sx[j]; q1 = sy[j]; q2 = sz[j];
+                    }
                     acc[0] += q0 * p0; acc[1] += q0 * p1; acc[2] += q0 * p2;
                     acc[3] += q1 * p0; acc[4] += q1 * p1; acc[5] += q1 * p2;
                     acc[6] += q2 * p0; acc[7] += q2 * p1; acc[8] += q2 * p2;
@@ -1185,13 +1293,13 @@ hipError_t apply(hipStream_t s, Soa3 P, size_t n, const double *solve_rec, const
     return hipGetLastError();
 }
 
-size_t batch_lds_bytes(size_t m) { return (3 * ((m + 31) / 32 * 32) + 48 + 48) * sizeof(double); }
+size_t batch_lds_bytes(size_t m) { return (4 * ((m + 31) / 32 * 32) + 48 + 48) * sizeof(double); }   // the larger layout (records)
 
 template <int PPL, int MODE>
 static hipError_t batch_launch(hipStream_t s, const double *P_in, const double *Q_in, size_t batch, size_t n, size_t m, unsigned iters,
                                double *P_out, double *rec_out, uint32_t *idx_out)
 {
-    const size_t lds = batch_lds_bytes(m);
+    const size_t lds = ((MODE == kExpanded ? 4 : 3) * ((m + 31) / 32 * 32) + 48 + 48) * sizeof(double);
     auto kern = batch_icp_kernel<PPL, MODE>;
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1206,11 +1314,13 @@ hipError_t batch_icp(hipStream_t s, int variant, const double *P_in, const doubl
                      unsigned iters, double *P_out, double *rec_out, uint32_t *idx_out)
 {
     if (batch == 0 || n == 0 || m == 0 || n > kBatchMaxN || m > kBatchMaxM || batch > 0x7FFFFFFFu) return hipErrorInvalidValue;
-    if (n <= 1024)
-        return variant == kFma ? batch_launch<4, kFma>(s, P_in, Q_in, batch, n, m, iters, P_out, rec_out, idx_out)
-                               : batch_launch<4, kExact>(s, P_in, Q_in, batch, n, m, iters, P_out, rec_out, idx_out);
-    return variant == kFma ? batch_launch<8, kFma>(s, P_in, Q_in, batch, n, m, iters, P_out, rec_out, idx_out)
-                           : batch_launch<8, kExact>(s, P_in, Q_in, batch, n, m, iters, P_out, rec_out, idx_out);
+#define ICPK_BATCH(PPL_) \
+    return variant == kExpanded ? batch_launch<PPL_, kExpanded>(s, P_in, Q_in, batch, n, m, iters, P_out, rec_out, idx_out) \
+           : variant == kFma    ? batch_launch<PPL_, kFma>(s, P_in, Q_in, batch, n, m, iters, P_out, rec_out, idx_out) \
+                                : batch_launch<PPL_, kExact>(s, P_in, Q_in, batch, n, m, iters, P_out, rec_out, idx_out)
+    if (n <= 1024) ICPK_BATCH(4);
+    ICPK_BATCH(8);
+#undef ICPK_BATCH
 }
 
 hipError_t fourth_root(hipStream_t s, const double *d2, size_t n, double *key)

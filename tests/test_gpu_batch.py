@@ -52,13 +52,46 @@ def test_batch_variants_and_limits():
     a = b.download()
     ms = b.run(5, search="fma", timed=True)
     c = b.download()
+    b.run(5, search="auto")                 # the expanded form on {-2q, |q|^2} records (default)
+    d = b.download()
     b.close()
     assert ms > 0
     for k in ("P_out", "idx", "R", "cov"):
         assert np.array_equal(a[k], c[k]), k
+        assert np.array_equal(a[k], d[k]), k
     for shape in ((1, 2049, 100), (1, 100, 4097), (0, 10, 10), (1, 0, 10)):
         with pytest.raises(icp_amd.IcpAmdError):
             icp_amd.Batch(*shape)
+
+
+def test_batch_expanded_form_is_only_a_filter():
+    """Default batch search (expanded form): scales / offsets that make its error bound loose or unusable, exact ties
+    (lattice, duplicated targets) and non-finite rows must give the EXACT variant's results bit for bit."""
+    rng = np.random.RandomState(8)
+    P, Q = synth.make_batch(4, 600)
+    cases = [(P * s + o, Q * s + o) for s, o in ((1.0, 0.0), (1e-6, 0.0), (1e6, 0.0), (1.0, 1e4), (1e-3, 50.0), (1e20, 0.0),
+                                                 (1e-20, 0.0), (1e150, 0.0), (1e-150, 0.0))]
+    ax = np.arange(-4, 4, dtype=np.float64)
+    L = np.stack(np.meshgrid(ax, ax, ax, indexing="ij"), -1).reshape(-1, 3)                     # 512 lattice points
+    Lq = np.stack([L[rng.permutation(512)] for _ in range(4)])
+    Lp = Lq[:, rng.permutation(512)] + np.array([0.5, 0.5, 0.0])                               # 4-way exact ties
+    cases.append((Lp, Lq))
+    Dq = Q.copy()
+    Dq[:, 300:] = Dq[:, :300]                                                                   # duplicated targets
+    cases.append((P, Dq))
+    Pn = P.copy()
+    Pn[0, 5, 0], Pn[1, 7, 1] = np.nan, np.inf
+    cases.append((Pn, Q))
+    for k, (Pc, Qc) in enumerate(cases):
+        b = icp_amd.Batch(Pc.shape[0], Pc.shape[1], Qc.shape[1])
+        b.upload(Pc, Qc)
+        b.run(3, search="exact")
+        want = b.download()
+        b.run(3, search="auto")
+        got = b.download()
+        b.close()
+        assert np.array_equal(want["idx"], got["idx"]), k
+        assert np.array_equal(want["P_out"], got["P_out"], equal_nan=True), k
 
 
 def test_cli_batch_argument(tmp_path):
