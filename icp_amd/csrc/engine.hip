@@ -306,8 +306,7 @@ static bool wants_grid(const icp_amd_engine *e)
 static void choose_geometry(icp_amd_engine *e)
 {
     // Every variant returns identical indices (each candidate is re-evaluated in the oracle's un-fused fp64 sequence);
-    // they differ in what the fast path costs per pair: EXACT 9.1 fp64 VALU instructions, FMA 7.1 fp64, F32 3.5 fp32.
-    // AUTO = F32, which degrades to FMA when the target's range makes the fp32 bound meaningless.
+    // they differ in what the fast path costs per pair: EXACT 9.1 fp64 VALU instructions, FMA 7.1 fp64, F32 2.0 packed fp32.
     // AUTO = GRID from kAutoGridMinTargets targets on, with F32 as the fallback while the clouds are so far from each
     // other that most search boxes are huge; F32 itself degrades to FMA when the fp32 bound is meaningless.
     int variant = requested_variant(e);
@@ -351,14 +350,8 @@ static void choose_geometry(icp_amd_engine *e)
     e->cb = cb;
 }
 
-// Launch geometry + the per-split (key, idx) scratch it needs; re-run whenever the source or the target changes.
-static int plan_search(icp_amd_engine *e)
+static int ensure_split_buffers(icp_amd_engine *e)
 {
-    if (wants_grid(e) && !e->grid_built) {
-        HIPCHK(grid_build(e->stream, e->Qz, e->m, &e->grid));
-        e->grid_built = true;
-    }
-    choose_geometry(e);
     const size_t need = (size_t)e->q_splits * e->n_pad;
     if (need > e->split_cap) {
         free_dev(e->keys); free_dev(e->idxs);
@@ -367,6 +360,20 @@ static int plan_search(icp_amd_engine *e)
         HIPCHK(hipMalloc(&e->idxs, need * sizeof(uint32_t)));
         e->split_cap = need;
     }
+    return ICP_AMD_OK;
+}
+
+// Launch geometry + the per-split (key, idx) scratch it needs; re-run whenever the source or the target changes.
+static int plan_search(icp_amd_engine *e)
+{
+    if (wants_grid(e) && !e->grid_built) {
+        HIPCHK(grid_build(e->stream, e->Qz, e->m, &e->grid));
+        e->grid_built = true;
+    }
+    choose_geometry(e);
+    // On the grid path the brute-force kernels are only AUTO's fallback: their scratch (12 bytes per source row and
+    // target split, 0.4 GB at 1M x 1M) is then allocated by the first fallback launch instead of here.
+    if (!e->use_grid) RCCHK(ensure_split_buffers(e));
     return ICP_AMD_OK;
 }
 
@@ -526,6 +533,7 @@ extern "C" int icp_amd_step_search(icp_amd_engine *e)
             if (e->bf_left) { --e->bf_left; grid = false; }
         }
         const int splits = grid ? 1 : (seed ? e->q_splits : e->q_splits_first);
+        if (!grid) RCCHK(ensure_split_buffers(e));
         if (grid) ++e->grid_launches; else ++e->bf_launches;
         if (grid)
             HIPCHK(search_grid(e->stream, e->P, e->n, e->pc, e->grid, e->Qz, e->m, seed ? e->idx : nullptr,
@@ -834,7 +842,10 @@ extern "C" int icp_amd_run_multi(const double *P, size_t n, const double *Q, siz
     if (n_gpus < 1 || n_gpus > avail) return fail(ICP_AMD_EINVAL, "icp_amd_run_multi: n_gpus=%d but %d device(s) are visible", n_gpus, avail);
     const int G = n_gpus;
     if (G == 1 && !devices) return icp_amd_run(P, n, Q, m, iters, ICP_AMD_METHOD_SHARED_LOOP, P_out, tr);
-    if (!g_rccl.load()) return fail(ICP_AMD_EHIP, "icp_amd_run_multi: cannot load librccl.so (%s)", dlerror() ? dlerror() : "missing symbols");
+    if (!g_rccl.load()) {
+        const char *why = dlerror();   // one call: the message is cleared by reading it
+        return fail(ICP_AMD_EHIP, "icp_amd_run_multi: cannot load librccl.so (%s)", why ? why : "missing symbols");
+    }
     MultiRun r;
     for (int g = 0; g < G; ++g) r.dev.push_back(devices ? devices[g] : g);
     const size_t cpr = icp_amd_chunks_per_rank(n, G), rpr = cpr * kChunk;
