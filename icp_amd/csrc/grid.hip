@@ -213,6 +213,17 @@ __device__ __forceinline__ void consider_rec(double ax, double ay, double az, co
 // One lane per source point.  A lane whose box is large (more than row_cap rows of cells or eval_cap targets -- an
 // outlier far from every target, or an un-seeded first pass) does not walk it alone while the other 63 lanes of its
 // wave wait: it records what it has found so far and queues the point for search_grid_overflow_kernel.
+// number of non-empty cells (added to *out)
+__global__ __launch_bounds__(kWG) void grid_occupied_kernel(const uint32_t *__restrict__ counts, size_t cells,
+                                                            unsigned long long *__restrict__ out)
+{
+    unsigned long long mine = 0;
+    for (size_t c = (size_t)blockIdx.x * kWG + threadIdx.x; c < cells; c += (size_t)gridDim.x * kWG) mine += counts[c] != 0;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) mine += __shfl_xor(mine, o, 64);
+    if ((threadIdx.x & 63) == 0 && mine) atomicAdd(out, mine);
+}
+
 __global__ __launch_bounds__(kWG) void search_grid_kernel(const double *__restrict__ px, const double *__restrict__ py,
                                                           const double *__restrict__ pz, const double *__restrict__ pc, size_t n,
                                                           GridDesc g, const uint32_t *__restrict__ start,
@@ -369,9 +380,10 @@ void grid_free(Grid *g)
     *g = Grid{};
 }
 
-// Cell size: about per_cell points per cell of the occupied volume (area / length when the cloud is flat along some
-// axes), at most 1024 cells per axis and 2^22 cells in all.
-static void choose_cells(const double lo[3], const double hi[3], size_t m, double per_cell, GridDesc *d)
+// Cell size: about per_cell points per cell of the bounding volume (area / length when the cloud is flat along some
+// axes) times h_scale, at most 1024 cells per axis and kMaxCells cells in all.
+constexpr double kMaxCells = 16777216.0;   // 2^24: 64 MB of cell starts
+static void choose_cells(const double lo[3], const double hi[3], size_t m, double per_cell, double h_scale, GridDesc *d)
 {
     double ext[3];
     int active = 0;
@@ -382,12 +394,13 @@ static void choose_cells(const double lo[3], const double hi[3], size_t m, doubl
     }
     double want = (double)m / per_cell;
     if (want < 1.0) want = 1.0;
-    if (want > 4194304.0) want = 4194304.0;
+    if (want > kMaxCells) want = kMaxCells;
     double h = active ? pow(vol / want, 1.0 / active) : 1.0;
     if (!(h > 0.0) || !(h < INFINITY)) {   // under/overflow of the volume: fall back to the longest axis
         const double longest = fmax(fmax(ext[0], ext[1]), ext[2]);
         h = longest > 0.0 ? longest / cbrt(want) : 1.0;
     }
+    h *= h_scale;
     for (;;) {
         double cells = 1.0;
         for (int k = 0; k < 3; ++k) {
@@ -399,7 +412,7 @@ static void choose_cells(const double lo[3], const double hi[3], size_t m, doubl
             d->dim[k] = dim;
             cells *= dim;
         }
-        if (cells <= 4194304.0) break;
+        if (cells <= kMaxCells) break;
         h *= 1.26;
     }
     double hmin = INFINITY;
@@ -414,7 +427,7 @@ static void choose_cells(const double lo[3], const double hi[3], size_t m, doubl
 }
 
 // Files the points into cells: g->start, g->perm and (with_coords) the sorted coordinates.
-static hipError_t grid_sort(hipStream_t s, Soa3 Qz, size_t m, double per_cell, bool with_coords, Grid *g)
+static hipError_t grid_sort(hipStream_t s, Soa3 Qz, size_t m, double per_cell, bool with_coords, bool refine, Grid *g)
 {
     grid_free(g);
     if (m == 0 || m > 0xFFFFFFF0u) return hipErrorInvalidValue;
@@ -447,18 +460,37 @@ static hipError_t grid_sort(hipStream_t s, Soa3 Qz, size_t m, double per_cell, b
             e = hipSuccess;
             goto done;
         }
-        choose_cells(lo, hi, m, per_cell, &g->d);
+        // Scans are surfaces: most cells of the bounding volume stay empty and the occupied ones are fuller than
+        // planned.  Count the occupied cells and shrink the cell edge until they hold about per_cell points on average
+        // (assuming the occupied count grows like 1/h^2; volume-filling clouds pass at once), within the cell budget.
+        GRID_TRY(hipMalloc(&cell, m * sizeof(uint32_t)));
+        double h_scale = 1.0;
+        for (int round = 0;; ++round) {
+            choose_cells(lo, hi, m, per_cell, h_scale, &g->d);
+            g->cells = (size_t)g->d.dim[0] * (size_t)g->d.dim[1] * (size_t)g->d.dim[2];
+            GRID_TRY(hipMalloc(&counts, g->cells * sizeof(uint32_t)));
+            GRID_TRY(hipMemsetAsync(counts, 0, g->cells * sizeof(uint32_t), s));
+            grid_count_kernel<<<(unsigned)((m + kWG - 1) / kWG), kWG, 0, s>>>(Qz.x, Qz.y, Qz.z, m, g->d, cell, counts);
+            GRID_TRY(hipGetLastError());
+            if (!refine || round == 3 || (double)g->cells > kMaxCells / 2.0) break;
+            unsigned long long occupied = 0;
+            GRID_TRY(hipMemsetAsync(bb, 0, sizeof(unsigned long long), s));
+            grid_occupied_kernel<<<256, kWG, 0, s>>>(counts, g->cells, bb);
+            GRID_TRY(hipGetLastError());
+            GRID_TRY(hipMemcpyAsync(&occupied, bb, sizeof occupied, hipMemcpyDeviceToHost, s));
+            GRID_TRY(hipStreamSynchronize(s));
+            const double avg = (double)m / (double)(occupied ? occupied : 1);
+            if (avg <= 2.0 * per_cell) break;
+            double f = sqrt(per_cell / avg);
+            h_scale *= f < 0.25 ? 0.25 : f;
+            (void)hipFree(counts);
+            counts = nullptr;
+        }
     }
-    g->cells = (size_t)g->d.dim[0] * (size_t)g->d.dim[1] * (size_t)g->d.dim[2];
     GRID_TRY(hipMalloc(&g->start, (g->cells + 1) * sizeof(uint32_t)));
     GRID_TRY(hipMalloc(&g->perm, m * sizeof(uint32_t)));
     if (with_coords) GRID_TRY(hipMalloc(&g->rec, m * sizeof(double4)));
-    GRID_TRY(hipMalloc(&cell, m * sizeof(uint32_t)));
-    GRID_TRY(hipMalloc(&counts, g->cells * sizeof(uint32_t)));
     GRID_TRY(hipMalloc(&cursor, g->cells * sizeof(uint32_t)));
-    GRID_TRY(hipMemsetAsync(counts, 0, g->cells * sizeof(uint32_t), s));
-    grid_count_kernel<<<(unsigned)((m + kWG - 1) / kWG), kWG, 0, s>>>(Qz.x, Qz.y, Qz.z, m, g->d, cell, counts);
-    GRID_TRY(hipGetLastError());
     grid_scan_kernel<<<1, 1024, 0, s>>>(counts, g->cells, g->start, cursor);
     GRID_TRY(hipGetLastError());
     grid_scatter_kernel<<<(unsigned)((m + kWG - 1) / kWG), kWG, 0, s>>>(Qz.x, Qz.y, Qz.z, m, cell, cursor, g->rec, g->perm);
@@ -484,7 +516,8 @@ static double env_per_cell(const char *name, double dflt)
 
 hipError_t grid_build(hipStream_t s, Soa3 Qz, size_t m, Grid *g)
 {
-    return grid_sort(s, Qz, m, env_per_cell("ICP_AMD_GRID_PER_CELL", 4.0), true, g);
+    const char *rf = getenv("ICP_AMD_GRID_REFINE");
+    return grid_sort(s, Qz, m, env_per_cell("ICP_AMD_GRID_PER_CELL", 4.0), true, !(rf && atoi(rf) == 0), g);
 }
 
 __global__ __launch_bounds__(kWG) void iota_kernel(uint32_t *out, size_t n)
@@ -500,7 +533,7 @@ hipError_t grid_order(hipStream_t s, Soa3 P, size_t n, uint32_t *order)
 {
     if (n == 0) return hipSuccess;
     Grid g;
-    hipError_t e = grid_sort(s, P, n, 128.0, false, &g);
+    hipError_t e = grid_sort(s, P, n, 128.0, false, false, &g);
     if (e != hipSuccess) return e;
     if (g.ok) {
         e = hipMemcpyAsync(order, g.perm, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, s);

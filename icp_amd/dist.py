@@ -4,7 +4,7 @@ over xGMI).  The reference has no multi-GPU path; this is new (SURVEY.md section
 Partitioning: rank r owns the source rows [r*rows_per_rank, (r+1)*rows_per_rank) (rows_per_rank a multiple of
 the 1024-row reduction chunk); the target cloud is replicated.  Per iteration there are two tiny exchanges, both
 all-gathers of per-chunk partial sums (12 doubles per chunk for the covariance, 3 for the centroid); every
-rank then sums ALL chunks in index order and solves R, t redundantly, so results are bit-identical on every
+rank then sums ALL chunks in the same fixed order and solves R, t redundantly, so results are bit-identical on every
 rank and independent of the number of GPUs, and no broadcast of R, t is needed.
 """
 import numpy as np

@@ -220,3 +220,24 @@ def test_grid_state_follows_target_and_source_replacement():
     b.close()
     for r in (got, again):
         assert np.array_equal(r[0], want[0]) and np.array_equal(r[1], want[1])
+
+
+def test_grid_on_surfaces_refines_its_cells_and_keeps_the_results(monkeypatch):
+    """Scan-like clouds (points on a surface): the cell edge is refined from the occupied-cell count; with and without
+    the refinement the correspondences equal the brute-force ones."""
+    rng = np.random.RandomState(12)
+    v = rng.standard_normal((30000, 3))
+    Q = v / np.linalg.norm(v, axis=1)[:, None] * np.array([1.0, 0.7, 0.5])
+    c, s = np.cos(0.04), np.sin(0.04)
+    P = Q[rng.permutation(30000)[:20000]] @ np.array([[c, -s, 0], [s, c, 0], [0, 0, 1.0]]).T + 1e-3 * rng.standard_normal((20000, 3))
+    outs = []
+    for search, refine in (("exact", "1"), ("grid", "1"), ("grid", "0")):
+        monkeypatch.setenv("ICP_AMD_GRID_REFINE", refine)
+        e = icp_amd.Engine(search=search)
+        e.set_target(Q)
+        e.set_source(P)
+        e.iterate(4)
+        outs.append((e.get_last()["idx"], e.get_source()))
+        e.close()
+    for o in outs[1:]:
+        assert np.array_equal(outs[0][0], o[0]) and np.array_equal(outs[0][1], o[1])
