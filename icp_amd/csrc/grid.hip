@@ -119,6 +119,59 @@ __global__ __launch_bounds__(1024) void grid_scan_kernel(const uint32_t *__restr
     if (threadIdx.x == 1023) start[cells] = part[1023];
 }
 
+// The same prefix sum in three launches for large grids: per-block sums (4096 cells per workgroup), their scan by
+// grid_scan_kernel, then the local scans.
+constexpr int kScanPerThread = 16;
+constexpr size_t kScanPerBlock = (size_t)kWG * kScanPerThread;
+
+__global__ __launch_bounds__(kWG) void grid_scan_sums_kernel(const uint32_t *__restrict__ counts, size_t cells,
+                                                             uint32_t *__restrict__ block_sums)
+{
+    __shared__ uint32_t part[kWG / 64];
+    const size_t b = (size_t)blockIdx.x * kScanPerBlock + (size_t)threadIdx.x * kScanPerThread;
+    uint32_t sum = 0;
+#pragma unroll
+    for (int k = 0; k < kScanPerThread; ++k)
+        if (b + k < cells) sum += counts[b + k];
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = (part[0] + part[1]) + (part[2] + part[3]);
+}
+
+__global__ __launch_bounds__(kWG) void grid_scan_apply_kernel(const uint32_t *__restrict__ counts, size_t cells,
+                                                              const uint32_t *__restrict__ block_off, uint32_t *__restrict__ start,
+                                                              uint32_t *__restrict__ cursor)
+{
+    __shared__ uint32_t part[kWG];
+    const size_t b = (size_t)blockIdx.x * kScanPerBlock + (size_t)threadIdx.x * kScanPerThread;
+    uint32_t c[kScanPerThread], sum = 0;
+#pragma unroll
+    for (int k = 0; k < kScanPerThread; ++k) {
+        c[k] = (b + k < cells) ? counts[b + k] : 0u;
+        sum += c[k];
+    }
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    for (int o = 1; o < kWG; o <<= 1) {
+        const uint32_t v = threadIdx.x >= (unsigned)o ? part[threadIdx.x - o] : 0u;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    uint32_t run = block_off[blockIdx.x] + (threadIdx.x ? part[threadIdx.x - 1] : 0u);
+#pragma unroll
+    for (int k = 0; k < kScanPerThread; ++k) {
+        if (b + k < cells) {
+            start[b + k] = run;
+            cursor[b + k] = run;
+        }
+        run += c[k];
+    }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == kWG - 1) start[cells] = run;
+}
+
 // targets sorted by cell: one 32-byte record {x, y, z, original index} each (one load per candidate), plus the index alone.  The order inside a cell is arbitrary (atomic
 // cursor); the search does not depend on it.
 __global__ __launch_bounds__(kWG) void grid_scatter_kernel(const double *__restrict__ qx, const double *__restrict__ qy,
@@ -433,7 +486,7 @@ static hipError_t grid_sort(hipStream_t s, Soa3 Qz, size_t m, double per_cell, b
     if (m == 0 || m > 0xFFFFFFF0u) return hipErrorInvalidValue;
     hipError_t e;
     unsigned long long *bb = nullptr;
-    uint32_t *cell = nullptr, *counts = nullptr, *cursor = nullptr;
+    uint32_t *cell = nullptr, *counts = nullptr, *cursor = nullptr, *block_sums = nullptr;
     unsigned long long host_bb[6];
 #define GRID_TRY(expr) do { e = (expr); if (e != hipSuccess) goto done; } while (0)
     GRID_TRY(hipMalloc(&bb, 6 * sizeof(unsigned long long)));
@@ -491,7 +544,18 @@ static hipError_t grid_sort(hipStream_t s, Soa3 Qz, size_t m, double per_cell, b
     GRID_TRY(hipMalloc(&g->perm, m * sizeof(uint32_t)));
     if (with_coords) GRID_TRY(hipMalloc(&g->rec, m * sizeof(double4)));
     GRID_TRY(hipMalloc(&cursor, g->cells * sizeof(uint32_t)));
-    grid_scan_kernel<<<1, 1024, 0, s>>>(counts, g->cells, g->start, cursor);
+    if (g->cells <= 65536) {
+        grid_scan_kernel<<<1, 1024, 0, s>>>(counts, g->cells, g->start, cursor);
+    } else {
+        const size_t blocks = (g->cells + kScanPerBlock - 1) / kScanPerBlock;   // <= 4096
+        GRID_TRY(hipMalloc(&block_sums, 3 * (blocks + 1) * sizeof(uint32_t)));
+        uint32_t *block_off = block_sums + blocks + 1, *unused_copy = block_off + blocks + 1;
+        grid_scan_sums_kernel<<<(unsigned)blocks, kWG, 0, s>>>(counts, g->cells, block_sums);
+        GRID_TRY(hipGetLastError());
+        grid_scan_kernel<<<1, 1024, 0, s>>>(block_sums, blocks, block_off, unused_copy);
+        GRID_TRY(hipGetLastError());
+        grid_scan_apply_kernel<<<(unsigned)blocks, kWG, 0, s>>>(counts, g->cells, block_off, g->start, cursor);
+    }
     GRID_TRY(hipGetLastError());
     grid_scatter_kernel<<<(unsigned)((m + kWG - 1) / kWG), kWG, 0, s>>>(Qz.x, Qz.y, Qz.z, m, cell, cursor, g->rec, g->perm);
     GRID_TRY(hipGetLastError());
@@ -503,6 +567,7 @@ done:
     if (cell) (void)hipFree(cell);
     if (counts) (void)hipFree(counts);
     if (cursor) (void)hipFree(cursor);
+    if (block_sums) (void)hipFree(block_sums);
     if (e != hipSuccess) grid_free(g);
     return e;
 }
