@@ -128,6 +128,7 @@ struct icp_amd_engine {
     // search
     int variant = kExact, ppl = 4, q_splits = 1, q_splits_first = 1, cb = 8;
     bool have_prev = false;     // idx holds the previous iteration's correspondences (search seed)
+    bool seed_enabled = true;   // ICP_AMD_SEED=0 switches seeding off (read when the search is planned)
     double *keys = nullptr;
     uint32_t *idxs = nullptr;
     size_t split_cap = 0;       // allocated q_splits * n_pad
@@ -371,6 +372,7 @@ static int plan_search(icp_amd_engine *e)
         e->grid_built = true;
     }
     choose_geometry(e);
+    e->seed_enabled = env_int("ICP_AMD_SEED", 1) != 0;
     // On the grid path the brute-force kernels are only AUTO's fallback: their scratch (12 bytes per source row and
     // target split, 0.4 GB at 1M x 1M) is then allocated by the first fallback launch instead of here.
     if (!e->use_grid) RCCHK(ensure_split_buffers(e));
@@ -519,7 +521,7 @@ extern "C" int icp_amd_step_search(icp_amd_engine *e)
             if (e->ev_used >= 4096) RCCHK(drain_events(e));
             RCCHK(time_begin(e, &a, &b));
         }
-        const bool seed = e->have_prev && env_int("ICP_AMD_SEED", 1) != 0;
+        const bool seed = e->have_prev && e->seed_enabled;
         bool grid = e->use_grid && e->gscratch.list && e->grid_out;
         if (grid && e->grid_auto) {
             // The queue length of the most recent grid launch that has finished (a mapped host word, read without

@@ -616,8 +616,7 @@ hipError_t search_grid(hipStream_t s, Soa3 P, size_t n, const double *pc, const 
 {
     if (!g.ok || m == 0 || m > 0xFFFFFFF0u) return hipErrorInvalidValue;
     if (n == 0) return hipSuccess;
-    const int row_cap = getenv("ICP_AMD_GRID_ROWCAP") ? atoi(getenv("ICP_AMD_GRID_ROWCAP")) : 64;
-    const int eval_cap = getenv("ICP_AMD_GRID_EVALCAP") ? atoi(getenv("ICP_AMD_GRID_EVALCAP")) : 768;
+    const int row_cap = sc ? sc->row_cap : 64, eval_cap = sc ? sc->eval_cap : 768;
     uint32_t *cnt = sc ? sc->count2 + sc->parity : nullptr, *cnt_next = sc ? sc->count2 + (sc->parity ^ 1) : nullptr;
     search_grid_kernel<<<(unsigned)((n + kWG - 1) / kWG), kWG, 0, s>>>(P.x, P.y, P.z, pc, n, g.d, g.start, g.rec, Qz.x, Qz.y, Qz.z,
                                                                       Qz.rec, (unsigned)m, idx_prev, P.rec, order, row_cap,
@@ -634,6 +633,9 @@ hipError_t search_grid(hipStream_t s, Soa3 P, size_t n, const double *pc, const 
 hipError_t grid_scratch_alloc(size_t n, GridScratch *sc)
 {
     grid_scratch_free(sc);
+    // what one lane may walk on its own before it hands its point to the overflow kernel (tunable for tests)
+    sc->row_cap = getenv("ICP_AMD_GRID_ROWCAP") ? atoi(getenv("ICP_AMD_GRID_ROWCAP")) : 64;
+    sc->eval_cap = getenv("ICP_AMD_GRID_EVALCAP") ? atoi(getenv("ICP_AMD_GRID_EVALCAP")) : 768;
     hipError_t e = hipMalloc(&sc->count2, 2 * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMemset(sc->count2, 0, 2 * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMalloc(&sc->list, (n ? n : 1) * sizeof(uint32_t));

@@ -86,6 +86,7 @@ struct GridScratch {
     volatile uint32_t *host_mem = nullptr;  // host address
     uint32_t *host_count = nullptr;         // device address of the same word
     int parity = 0;
+    int row_cap = 64, eval_cap = 768;       // rows of cells / targets one lane walks alone (read from the environment at allocation)
 };
 hipError_t grid_scratch_alloc(size_t n, GridScratch *sc);
 void grid_scratch_free(GridScratch *sc);
