@@ -1114,9 +1114,8 @@ extern "C" int icp_amd_correspondences(const double *P, size_t n, const double P
                               keys.as<double>(), idxs.as<uint32_t>()));
         } else {   // range outside the fp32 bound's domain: same degradation as the engine
             if (ppl == 8) ppl = 4;
-            const size_t t64 = m_pad / kTileQ;
-            HIPCHK(search(s, kFma, ppl, cb, dP, n_pad, pc.as<double>(), dQ, m, m_pad, q_splits > (int)t64 ? (int)t64 : q_splits,
-                          nullptr, keys.as<double>(), idxs.as<uint32_t>()));
+            HIPCHK(search(s, kFma, ppl, cb, dP, n_pad, pc.as<double>(), dQ, m, m_pad, q_splits, nullptr, keys.as<double>(),
+                          idxs.as<uint32_t>()));
         }
     } else {
         HIPCHK(search(s, variant, ppl, cb, dP, n_pad, pc.as<double>(), dQ, m, m_pad, q_splits, nullptr, keys.as<double>(),

@@ -246,3 +246,25 @@ def test_cli_matches_reference_output(tmp_path):
     assert r.returncode != 0 and "Usage: ./GPUICP file1 file2 nbiters method" in r.stderr
     r = subprocess.run([exe, str(pf), str(qf), "5", "-fast"], cwd=tmp_path, capture_output=True, text=True, timeout=60)
     assert r.returncode != 0 and "Invalid method, must be: -shared|-loop|-shared-loop|-batch" in r.stderr
+
+
+def test_stage_level_f32_fallback_uses_the_requested_splits():
+    """Regression (found by tools/fuzz_variants.py): a target whose range defeats the fp32 bound makes the stage-level
+    F32 search fall back to FMA; it must run with the same number of target splits the merge then reads."""
+    rng = np.random.RandomState(4)
+    for n, m, scale in ((2799, 142, 1e22), (1768, 796, 1e-25), (128, 3196, 1e17)):
+        P, Q = rng.uniform(-1, 1, (n, 3)) * scale, rng.uniform(-1, 1, (m, 3)) * scale
+        Pc, Qz = orc.mean0(P), Q - orc.mean0(Q)
+        want = orc.correspondences(P - Pc, Qz, nthreads=4)
+        for splits in (1, 3, 6, 8):
+            assert np.array_equal(icp_amd.correspondences(P, Pc, Qz, search="f32", q_splits=splits), want), (n, m, scale, splits)
+
+
+def test_differential_fuzz_of_all_variants_short():
+    """A few seconds of tools/fuzz_variants.py: lattices, duplicates, clusters, few-ulp near-ties, wild scales, flat clouds;
+    every search variant, stage level and seeded engine iterations, against the oracle."""
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_variants.py"), "8", "11"], capture_output=True, text=True,
+                       timeout=200)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "mismatches 0" in r.stdout
