@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Differential fuzzing of the multi-registration kernel: default (expanded form) vs EXACT variant vs the engine run
+alone on the same pair, on adversarial small clouds.  Exit code 1 on a mismatch."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import icp_amd
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+t_end = time.time() + budget
+cases = bad = 0
+while time.time() < t_end:
+    B, n, m = int(rng.randint(1, 6)), int(rng.randint(1, 2049)), int(rng.randint(1, 4097))
+    iters = int(rng.randint(1, 5))
+    kind = rng.randint(5)
+    if kind == 0:
+        Q = rng.randint(-5, 6, (B, m, 3)).astype(np.float64)
+        P = rng.randint(-5, 6, (B, n, 3)).astype(np.float64) + rng.choice([0.0, 0.5], (B, n, 3))
+    elif kind == 1:
+        base = rng.uniform(-1, 1, (B, max(1, m // 3), 3))
+        Q = np.stack([base[b][rng.randint(0, base.shape[1], m)] for b in range(B)])
+        P = rng.uniform(-1, 1, (B, n, 3))
+    elif kind == 2:
+        s = 10.0 ** rng.uniform(-160, 150)
+        o = rng.choice([0.0, 1.0, 1e4])
+        Q = rng.uniform(-1, 1, (B, m, 3)) * s + o * s
+        P = rng.uniform(-1, 1, (B, n, 3)) * s + o * s
+    elif kind == 3:
+        Q = rng.uniform(-1, 1, (B, m, 3)) * np.array([1.0, rng.choice([0.0, 1e-9, 1.0]), rng.choice([0.0, 1.0])])
+        P = rng.uniform(-1, 1, (B, n, 3))
+    else:
+        Q = rng.uniform(-1, 1, (B, m, 3))
+        c, s_ = np.cos(0.1), np.sin(0.1)
+        P = Q[:, rng.randint(0, m, n)] @ np.array([[c, -s_, 0], [s_, c, 0], [0, 0, 1.0]]).T + 1e-3 * rng.standard_normal((B, n, 3))
+    b = icp_amd.Batch(B, n, m)
+    b.upload(P, Q)
+    b.run(iters, search="exact"); want = b.download()
+    b.run(iters, search="auto"); got = b.download()
+    b.close()
+    ok = np.array_equal(want["idx"], got["idx"]) and np.array_equal(want["P_out"], got["P_out"], equal_nan=True)
+    one, tr = icp_amd.icp_gpu_optimized(P[0], Q[0], iters, trace=True)
+    ok1 = np.array_equal(tr["idx"][-1], got["idx"][0]) and np.array_equal(one, got["P_out"][0], equal_nan=True)
+    if not (ok and ok1):
+        bad += 1
+        print("MISMATCH kind=%d B=%d n=%d m=%d iters=%d variants_equal=%s engine_equal=%s" % (kind, B, n, m, iters, ok, ok1), flush=True)
+    cases += 1
+print("cases %d, mismatches %d" % (cases, bad), flush=True)
+sys.exit(1 if bad else 0)
