@@ -177,3 +177,21 @@ def test_cpp_adaptor_compiles_against_reference_types(tmp_path):
     r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-I", ref_inc, "-I", os.path.join(ROOT, "include"), str(src)],
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+
+
+def test_tie_band_covers_every_key_preimage():
+    """The search kernels treat every d^2 within 2^-48 (relative, + 1e-300) of the best as a possible key tie
+    (exact.h tie_band).  The key is sqrt(sqrt(d^2)), correctly rounded twice: the doubles that share one key form a run
+    of at most 9, i.e. less than half the band."""
+    rng = np.random.RandomState(0)
+    d = np.concatenate([rng.uniform(1, 16, 200000), 10.0 ** rng.uniform(-300, 300, 200000), rng.uniform(0, 1e-305, 1000)])
+    k0 = np.sqrt(np.sqrt(d))
+    hi = d.copy()
+    alive = np.ones(len(d), bool)
+    top = d.copy()
+    for _ in range(24):
+        hi = np.nextafter(hi, np.inf)
+        alive &= np.sqrt(np.sqrt(hi)) == k0
+        top = np.where(alive, hi, top)
+    assert not alive.any()                                  # every run ended within 24 steps
+    assert np.all(top <= d * (1 + 2.0 ** -48) + 1e-300)     # and inside the band
