@@ -268,3 +268,24 @@ def test_differential_fuzz_of_all_variants_short():
                        timeout=200)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "mismatches 0" in r.stdout
+
+
+def test_cli_on_the_cow_pair_20_iterations(tmp_path):
+    """BASELINE config 2 through the executable: `GPUICP cow_tr1 cow_ref 20 -shared-loop` (inputs from the golden
+    fixture, written as CSV with the reference's header) reproduces the reference CPUICP result file and its report."""
+    exe = os.path.join(ROOT, "bin", "GPUICP")
+    g = golden("cow_tr1")
+    for name, A in (("P.txt", g["P"]), ("Q.txt", g["Q"])):
+        with open(tmp_path / name, "w") as f:
+            f.write("Points_0,Points_1,Points_2\n")
+            for r in A:
+                f.write("%.17g,%.17g,%.17g\n" % tuple(r))
+    env = dict(os.environ, ICP_AMD_RESULT_FILE=str(tmp_path / "out.npy"))
+    r = subprocess.run([exe, "P.txt", "Q.txt", str(int(g["iters"])), "-shared-loop"], cwd=tmp_path, capture_output=True, text=True,
+                       timeout=120, env=env)
+    assert r.returncode == 0, r.stderr
+    want_report = orc.euclidian_distance(g["Q"], g["P_out"])
+    assert abs(float(r.stdout.split(":")[1]) - want_report) <= 1e-6 * max(1.0, want_report)   # printed with 6 digits
+    assert relerr(np.load(tmp_path / "out.npy"), g["P_out"]) < TOL
+    lines = open(tmp_path / "point_cloud_result").read().split("\n")
+    assert lines[0] == " dim0: %d dim1: 3 array: " % len(g["P"])
