@@ -286,7 +286,8 @@ __global__ __launch_bounds__(kWG) void search_grid_kernel(const double *__restri
                                                           unsigned m,
                                                           const uint32_t *__restrict__ idx_prev,
                                                           const double4 *__restrict__ prec, const uint32_t *__restrict__ order,
-                                                          int row_cap, unsigned eval_cap, uint32_t *__restrict__ ovf_count,
+                                                          int row_cap, unsigned eval_cap, int defer_always,
+                                                          uint32_t *__restrict__ ovf_count,
                                                           uint32_t *__restrict__ ovf_list, double2 *__restrict__ out_rec)
 {
     const size_t l = (size_t)blockIdx.x * kWG + threadIdx.x;
@@ -327,9 +328,17 @@ __global__ __launch_bounds__(kWG) void search_grid_kernel(const double *__restri
     bool defer = false;
     for (;;) {
         const Box b = make_box(g, ax, ay, az, r);
-        if (ovf_list && (long)(b.cy1 - b.cy0 + 1) * (long)(b.cz1 - b.cz0 + 1) > (long)row_cap) {
-            defer = true;
-            break;
+        if (ovf_list) {
+            // A large box is handed over when it would keep this lane busy while most of its wave idles (an outlier);
+            // when most lanes of the wave have large boxes (an un-seeded pass over a scan, whose cells are mostly empty)
+            // they all walk their own, up to 16 times the caps.
+            const long rows = (long)(b.cy1 - b.cy0 + 1) * (long)(b.cz1 - b.cz0 + 1);
+            const bool big = rows > (long)row_cap;
+            const int n_big = __popcll(__ballot(big)), n_act = __popcll(__ballot(true));
+            if (big && (defer_always || rows > 16L * row_cap || 4 * n_big < n_act)) {
+                defer = true;
+                break;
+            }
         }
         for (int cz = b.cz0; cz <= b.cz1 && !defer; ++cz) {
             for (int cy = b.cy0; cy <= b.cy1; ++cy) {
@@ -338,8 +347,11 @@ __global__ __launch_bounds__(kWG) void search_grid_kernel(const double *__restri
                 const uint32_t k0 = start[row + b.cx0], k1 = start[row + b.cx1 + 1];
                 evals += k1 - k0;
                 if (ovf_list && evals > eval_cap) {
-                    defer = true;
-                    break;
+                    const int n_big = __popcll(__ballot(true));   // lanes of the wave that are past the cap here, roughly
+                    if (defer_always || evals > 16u * eval_cap || 4 * n_big < 64) {
+                        defer = true;
+                        break;
+                    }
                 }
                 for (uint32_t k = k0; k < k1; ++k) consider_rec(ax, ay, az, rec[k], dmin, edge, bk, bj);
             }
@@ -620,7 +632,8 @@ hipError_t search_grid(hipStream_t s, Soa3 P, size_t n, const double *pc, const 
     uint32_t *cnt = sc ? sc->count2 + sc->parity : nullptr, *cnt_next = sc ? sc->count2 + (sc->parity ^ 1) : nullptr;
     search_grid_kernel<<<(unsigned)((n + kWG - 1) / kWG), kWG, 0, s>>>(P.x, P.y, P.z, pc, n, g.d, g.start, g.rec, Qz.x, Qz.y, Qz.z,
                                                                       Qz.rec, (unsigned)m, idx_prev, P.rec, order, row_cap,
-                                                                      (unsigned)eval_cap, cnt, sc ? sc->list : nullptr, out_rec);
+                                                                      (unsigned)eval_cap, sc ? sc->defer_always : 0, cnt,
+                                                                      sc ? sc->list : nullptr, out_rec);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || !sc) return e;
     size_t wgs = n < 2048 ? n : 2048;
@@ -636,6 +649,7 @@ hipError_t grid_scratch_alloc(size_t n, GridScratch *sc)
     // what one lane may walk on its own before it hands its point to the overflow kernel (tunable for tests)
     sc->row_cap = getenv("ICP_AMD_GRID_ROWCAP") ? atoi(getenv("ICP_AMD_GRID_ROWCAP")) : 64;
     sc->eval_cap = getenv("ICP_AMD_GRID_EVALCAP") ? atoi(getenv("ICP_AMD_GRID_EVALCAP")) : 768;
+    sc->defer_always = getenv("ICP_AMD_GRID_DEFER") && !strcmp(getenv("ICP_AMD_GRID_DEFER"), "always");
     hipError_t e = hipMalloc(&sc->count2, 2 * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMemset(sc->count2, 0, 2 * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMalloc(&sc->list, (n ? n : 1) * sizeof(uint32_t));

@@ -87,6 +87,7 @@ struct GridScratch {
     uint32_t *host_count = nullptr;         // device address of the same word
     int parity = 0;
     int row_cap = 64, eval_cap = 768;       // rows of cells / targets one lane walks alone (read from the environment at allocation)
+    int defer_always = 0;                   // 1: hand over every box above the caps (tests); 0: only when most of the wave would idle
 };
 hipError_t grid_scratch_alloc(size_t n, GridScratch *sc);
 void grid_scratch_free(GridScratch *sc);

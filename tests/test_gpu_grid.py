@@ -139,6 +139,7 @@ def test_grid_overflow_queue_and_auto_fallback(monkeypatch):
     P, Q = synth.make_pair(6000, 7000, seed=5)
     Pc, Qz = orc.mean0(P), Q - orc.mean0(Q)
     want = orc.correspondences(P - Pc, Qz, nthreads=4)
+    monkeypatch.setenv("ICP_AMD_GRID_DEFER", "always")
     for rowcap, evalcap in ((1, 8), (64, 1), (2, 100000)):
         monkeypatch.setenv("ICP_AMD_GRID_ROWCAP", str(rowcap))
         monkeypatch.setenv("ICP_AMD_GRID_EVALCAP", str(evalcap))
@@ -151,6 +152,11 @@ def test_grid_overflow_queue_and_auto_fallback(monkeypatch):
         e.close()
         ref = orc.icp(P, Q, 3, trace=True, nthreads=4)
         assert np.array_equal(got, ref["idx"][-1]), (rowcap, evalcap)
+    monkeypatch.delenv("ICP_AMD_GRID_DEFER")
+    for rowcap, evalcap in ((1, 8), (2, 16)):       # default rule: boxes up to 16x the caps are walked when the whole wave has them
+        monkeypatch.setenv("ICP_AMD_GRID_ROWCAP", str(rowcap))
+        monkeypatch.setenv("ICP_AMD_GRID_EVALCAP", str(evalcap))
+        assert np.array_equal(icp_amd.correspondences(P, Pc, Qz, search="grid"), want), (rowcap, evalcap)
     monkeypatch.delenv("ICP_AMD_GRID_ROWCAP")
     monkeypatch.delenv("ICP_AMD_GRID_EVALCAP")
     # outliers: a tenth of the source points far away from every target, and a source that overlaps half the target
