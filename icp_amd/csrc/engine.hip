@@ -294,8 +294,9 @@ static int requested_variant(const icp_amd_engine *e)
     if (sv && !strcmp(sv, "auto")) variant = 0;
     return variant;
 }
-// AUTO searches on the grid from this many targets on (below, one brute-force launch is as cheap as it gets).
-static const size_t kAutoGridMinTargets = 2048;
+// AUTO searches on the grid from this many targets on: the grid saves 18 us per iteration at 1000 targets (36 at 2000)
+// and costs about 250 us more to set up (tools/tiny_probe.py), so it pays from roughly 15 iterations on here.
+static const size_t kAutoGridMinTargets = 1024;
 static bool wants_grid(const icp_amd_engine *e)
 {
     const int v = requested_variant(e);

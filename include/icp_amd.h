@@ -44,7 +44,7 @@ extern "C" {
 #define ICP_AMD_METHOD_BATCH       3
 
 /* Correspondence-search kernel variants (engine option `search`); every variant returns identical indices. */
-#define ICP_AMD_SEARCH_AUTO   0   /* GRID from 2048 targets on (F32 while most search boxes are huge), else F32;
+#define ICP_AMD_SEARCH_AUTO   0   /* GRID from 1024 targets on (F32 while most search boxes are huge), else F32;
                                      F32 itself degrades to FMA when the clouds' range defeats the fp32 bound  */
 #define ICP_AMD_SEARCH_EXACT  1   /* 8 un-fused fp64 ops per pair, the oracle's own sequence                */
 #define ICP_AMD_SEARCH_FMA    2   /* fused fp64 pre-filter + exact re-evaluation of every candidate         */

@@ -198,7 +198,7 @@ def test_grid_overflow_queue_and_auto_fallback(monkeypatch):
 def test_grid_state_follows_target_and_source_replacement():
     """AUTO decides per target: a small target (brute force) replaced by a large one under the same source switches to
     the grid, and back; a new source under the same target rebuilds the per-source records.  Results = brute force."""
-    P, Qs = synth.make_pair(5000, 1500, seed=41)
+    P, Qs = synth.make_pair(5000, 900, seed=41)
     _, Ql = synth.make_pair(5000, 9000, seed=42)
     e = icp_amd.Engine()
     e.set_target(Qs)
