@@ -15,10 +15,19 @@ def short(name):
 
 
 def stats(db):
+    """rocprofv3 --kernel-trace --stats: calls, total, average and share as rocprofv3 reports them (top_kernels view), plus
+    the median and minimum duration per kernel from the trace itself (the first search launch of a run is un-seeded and
+    slower, so the median is the figure to hold against bench.py's hipEvent average over the timed, seeded launches)."""
     c = sqlite3.connect(db)
-    print("%-44s %6s %14s %14s %8s" % ("kernel", "calls", "total_us", "avg_us", "pct"))
+    durs = defaultdict(list)
+    for name, s, e in c.execute("select name,start,end from kernels"):
+        durs[short(name)[:44]].append(e - s)
+    print("%-44s %6s %14s %14s %14s %14s %8s" % ("kernel", "calls", "total_us", "avg_us", "median_us", "min_us", "pct"))
     for name, calls, tot, avg, pct in c.execute("select name,total_calls,total_duration,average,percentage from top_kernels"):
-        print("%-44s %6d %14.3f %14.3f %8.3f" % (short(name)[:44], calls, tot / 1e3, avg / 1e3, pct))
+        k = short(name)[:44]
+        d = sorted(durs.get(k, [0]))
+        # top_kernels reports microseconds, the trace nanoseconds
+        print("%-44s %6d %14.3f %14.3f %14.3f %14.3f %8.3f" % (k, calls, tot, avg, d[len(d) // 2] / 1e3, d[0] / 1e3, pct))
 
 
 def pmc(db):
