@@ -25,7 +25,7 @@ $(LIB): $(CSRC)/kernels.o $(CSRC)/grid.o $(CSRC)/engine.o $(CSRC)/hostio.o
 
 bin/GPUICP: $(CSRC)/gpuicp_main.cpp $(LIB) include/icp_amd.h
 	@mkdir -p bin
-	$(CXX) -O2 -std=c++17 -Wall -Wextra -o $@ $(CSRC)/gpuicp_main.cpp -Licp_amd -licp_amd -Wl,-rpath,'$$ORIGIN/../icp_amd'
+	$(CXX) -O2 -std=c++17 -Wall -Wextra -pthread -o $@ $(CSRC)/gpuicp_main.cpp -Licp_amd -licp_amd -Wl,-rpath,'$$ORIGIN/../icp_amd'
 
 oracle:
 	$(MAKE) -C oracle all

@@ -8,6 +8,7 @@
 // (include/error.cuh:3-9).
 #include <cstdio>
 #include <cstdlib>
+#include <future>
 #include <iostream>
 #include <stdexcept>
 #include <string>
@@ -35,8 +36,16 @@ int main(int argc, char **argv)
     runtime_assert(argc == 5 || (argc == 6 && std::string(argv[4]) == "-batch"),
                    "Usage: ./GPUICP file1 file2 nbiters method={-loop|-batch|-shared|-shared-loop}");
     size_t Pl, Pc, Ql, Qc;
-    std::vector<double> P = load(argv[1], Pl, Pc);
-    std::vector<double> Q = load(argv[2], Ql, Qc);
+    // the two files are independent: parse them at the same time (errors surface in file order, like the reference)
+    std::future<std::vector<double>> Qf = std::async(std::launch::async, [&] { return load(argv[2], Ql, Qc); });
+    std::vector<double> P;
+    try {
+        P = load(argv[1], Pl, Pc);
+    } catch (...) {
+        Qf.wait();
+        throw;
+    }
+    std::vector<double> Q = Qf.get();
     const unsigned nbiters = (unsigned)std::stoi(argv[3]);
     const std::string method{argv[4]};
     runtime_assert(method == "-batch" || method == "-loop" || method == "-shared" || method == "-shared-loop",

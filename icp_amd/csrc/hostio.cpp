@@ -377,17 +377,40 @@ extern "C" int icp_amd_write_cloud_binary(const char *path, const double *A, siz
 
 // " dim0: N dim1: C array: " then one line per row, every value followed by a blank, default ostream
 // formatting (= %g, 6 significant digits).
+static void format_rows(const double *A, size_t r0, size_t r1, size_t cols, std::string *out)
+{
+    char buf[64];
+    out->reserve((r1 - r0) * (cols * 12 + 1));
+    for (size_t i = r0; i < r1; ++i) {
+        for (size_t j = 0; j < cols; ++j) {
+            const int k = snprintf(buf, sizeof buf, "%g ", A[i * cols + j]);
+            out->append(buf, (size_t)k);
+        }
+        out->push_back('\n');
+    }
+}
+
 extern "C" int icp_amd_write_cloud(const char *path, const double *A, size_t rows, size_t cols)
 {
     if (!path || (!A && rows != 0 && cols != 0)) return io_fail(ICP_AMD_EINVAL, "icp_amd_write_cloud: NULL argument");
     FILE *f = fopen(path, "w");
     if (!f) return io_fail(ICP_AMD_EIO, "File could not be opened !");
     fprintf(f, " dim0: %zu dim1: %zu array: \n", rows, cols);
-    for (size_t i = 0; i < rows; ++i) {
-        for (size_t j = 0; j < cols; ++j) fprintf(f, "%g ", A[i * cols + j]);
-        fputc('\n', f);
+    // the rows are formatted by several threads (same snprintf, so the same bytes) and written in order
+    size_t threads = std::min<size_t>(std::max(1u, std::thread::hardware_concurrency()), 16);
+    if (rows * cols < 65536) threads = 1;
+    std::vector<std::string> part(threads);
+    std::vector<std::thread> pool;
+    const size_t per = (rows + threads - 1) / threads;
+    for (size_t t = 1; t < threads; ++t) {
+        const size_t r0 = std::min(rows, t * per), r1 = std::min(rows, r0 + per);
+        pool.emplace_back(format_rows, A, r0, r1, cols, &part[t]);
     }
-    if (fclose(f) != 0) return io_fail(ICP_AMD_EIO, "write failed");
+    format_rows(A, 0, std::min(rows, per), cols, &part[0]);
+    for (std::thread &th : pool) th.join();
+    bool ok = true;
+    for (const std::string &p : part) ok = ok && (p.empty() || fwrite(p.data(), 1, p.size(), f) == p.size());
+    if (fclose(f) != 0 || !ok) return io_fail(ICP_AMD_EIO, "write failed");
     return ICP_AMD_OK;
 }
 
