@@ -11,7 +11,11 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 t_end = time.time() + budget
 cases = bad = 0
+t_say = time.time() + 30
 while time.time() < t_end:
+    if time.time() > t_say:
+        print("... %d cases, %d mismatches so far" % (cases, bad), flush=True)
+        t_say = time.time() + 30
     B, n, m = int(rng.randint(1, 6)), int(rng.randint(1, 2049)), int(rng.randint(1, 4097))
     iters = int(rng.randint(1, 5))
     kind = rng.randint(5)

@@ -15,7 +15,11 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 t_end = time.time() + budget
 cases = bad = 0
+t_say = time.time() + 30
 while time.time() < t_end:
+    if time.time() > t_say:
+        print("... %d cases, %d mismatches so far" % (cases, bad), flush=True)
+        t_say = time.time() + 30
     n, m, world, iters = int(rng.randint(1, 40000)), int(rng.randint(1, 30000)), int(rng.randint(2, 9)), int(rng.randint(1, 4))
     P, Q = synth.make_pair(n, max(n, m), seed=int(rng.randint(1 << 30)))
     Q = Q[:m] if m < len(Q) else Q

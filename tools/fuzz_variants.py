@@ -12,7 +12,11 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 t_end = time.time() + budget
 cases = bad = 0
+t_say = time.time() + 30
 while time.time() < t_end:
+    if time.time() > t_say:
+        print("... %d cases, %d mismatches so far" % (cases, bad), flush=True)
+        t_say = time.time() + 30
     n, m = int(rng.randint(1, 3000)), int(rng.randint(1, 5000))
     kind = rng.randint(6)
     if kind == 0:      # integer lattice, exact ties
