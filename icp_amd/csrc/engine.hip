@@ -548,8 +548,8 @@ extern "C" int icp_amd_step_search(icp_amd_engine *e)
             HIPCHK(search(e->stream, e->variant, e->ppl, e->cb, e->P, e->n_pad, e->pc, e->Qz, e->m, e->m_pad, splits,
                           seed ? e->idx : nullptr, e->keys, e->idxs));
         if (e->opt.kernel_timing) HIPCHK(hipEventRecord(b, e->stream));
-        HIPCHK(merge_cov(e->stream, e->P, e->n, e->n_pad, e->pc, e->Qz, e->m, splits, e->keys, e->idxs, grid ? e->grid_out : nullptr,
-                         e->idx, e->reject_d2, cov_slot));
+        HIPCHK(merge_cov(e->stream, e->P, e->n, e->n_pad, e->pc, e->Qz, e->m, splits, e->keys, e->idxs,
+                         grid && !e->P.rec ? e->grid_out : nullptr, grid && e->P.rec, e->idx, e->reject_d2, cov_slot));
         e->have_prev = true;
     }
     return ICP_AMD_OK;
@@ -1123,7 +1123,7 @@ extern "C" int icp_amd_correspondences(const double *P, size_t n, const double P
                       idxs.as<uint32_t>()));
     }
     HIPCHK(merge_cov(s, dP, n, n_pad, pc.as<double>(), dQ, m, q_splits, keys.as<double>(), idxs.as<uint32_t>(),
-                     grid ? grec.as<double2>() : nullptr, out.as<uint32_t>(), std::numeric_limits<double>::infinity(),
+                     grid ? grec.as<double2>() : nullptr, false, out.as<uint32_t>(), std::numeric_limits<double>::infinity(),
                      part.as<double>()));
     HIPCHK(hipMemcpyAsync(idx, out.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));

@@ -232,19 +232,22 @@ __device__ __forceinline__ double next_radius(double edge, double r)
     return (edge < INFINITY) ? __builtin_fmax(sqrt(edge) * (1.0 + 0x1p-10), r * 1.0625) : 2.0 * r;
 }
 // One evaluated target: lexicographic (key, index) best among the candidates inside the tie band of the running minimum.
-__device__ __forceinline__ void consider(double d, uint32_t j, double &dmin, double &edge, double &bk, uint32_t &bj)
+__device__ __forceinline__ bool consider(double d, uint32_t j, double &dmin, double &edge, double &bk, uint32_t &bj)
 {
+    bool took = false;
     if (d <= edge && d < INFINITY) {
         const double key = key_of(d);
         if (key < bk || (key == bk && j < bj)) {
             bk = key;
             bj = j;
+            took = true;
         }
         if (d < dmin) {
             dmin = d;
             edge = tie_band(d);
         }
     }
+    return took;
 }
 
 __device__ __forceinline__ double seed_d2(double ax, double ay, double az, uint32_t js, const double *__restrict__ qx,
@@ -261,6 +264,16 @@ __device__ __forceinline__ void consider_rec(double ax, double ay, double az, co
                                              double &bk, uint32_t &bj)
 {
     consider(d2_exact(ax, ay, az, v.x, v.y, v.z), (uint32_t)__double_as_longlong(v.w), dmin, edge, bk, bj);
+}
+// same, also remembering the coordinates of the best target (they go back into the source row's record)
+__device__ __forceinline__ void consider_rec(double ax, double ay, double az, const double4 v, double &dmin, double &edge,
+                                             double &bk, uint32_t &bj, double &bx, double &by, double &bz)
+{
+    if (consider(d2_exact(ax, ay, az, v.x, v.y, v.z), (uint32_t)__double_as_longlong(v.w), dmin, edge, bk, bj)) {
+        bx = v.x;
+        by = v.y;
+        bz = v.z;
+    }
 }
 
 // One lane per source point.  A lane whose box is large (more than row_cap rows of cells or eval_cap targets -- an
@@ -285,7 +298,7 @@ __global__ __launch_bounds__(kWG) void search_grid_kernel(const double *__restri
                                                           const double *__restrict__ qz, const double4 *__restrict__ qrec4,
                                                           unsigned m,
                                                           const uint32_t *__restrict__ idx_prev,
-                                                          const double4 *__restrict__ prec, const uint32_t *__restrict__ order,
+                                                          double4 *__restrict__ prec, const uint32_t *__restrict__ order,
                                                           int row_cap, unsigned eval_cap, int defer_always,
                                                           uint32_t *__restrict__ ovf_count,
                                                           uint32_t *__restrict__ ovf_list, double2 *__restrict__ out_rec)
@@ -311,11 +324,17 @@ __global__ __launch_bounds__(kWG) void search_grid_kernel(const double *__restri
     uint32_t bj = 0xFFFFFFFFu;
     const double amax = __builtin_fmax(__builtin_fmax(__builtin_fabs(ax), __builtin_fabs(ay)), __builtin_fabs(az));
     if (!(amax < INFINITY) || ax != ax || ay != ay || az != az) {   // every d^2 is inf or NaN: no correspondence
-        out_rec[i] = make_double2(bk, __longlong_as_double((long long)bj));
+        if (prec) prec[2 * i + 1] = make_double4(0.0, 0.0, 0.0, __longlong_as_double((long long)bj));
+        else out_rec[i] = make_double2(bk, __longlong_as_double((long long)bj));
         return;
     }
+    if (!prec && js < m) {   // the coordinates of the seed, for the result record
+        sqx = qrec4 ? qrec4[js].x : qx[js];
+        sqy = qrec4 ? qrec4[js].y : qy[js];
+        sqz = qrec4 ? qrec4[js].z : qz[js];
+    }
     if (js < m) {
-        const double d = prec ? d2_exact(ax, ay, az, sqx, sqy, sqz) : seed_d2(ax, ay, az, js, qx, qy, qz, qrec4);
+        const double d = d2_exact(ax, ay, az, sqx, sqy, sqz);
         if (d < INFINITY) {
             dmin = d;
             bk = key_of(d);
@@ -353,13 +372,16 @@ __global__ __launch_bounds__(kWG) void search_grid_kernel(const double *__restri
                         break;
                     }
                 }
-                for (uint32_t k = k0; k < k1; ++k) consider_rec(ax, ay, az, rec[k], dmin, edge, bk, bj);
+                for (uint32_t k = k0; k < k1; ++k) consider_rec(ax, ay, az, rec[k], dmin, edge, bk, bj, sqx, sqy, sqz);
             }
         }
         if (defer || b.all || b.B > edge) break;
         r = next_radius(edge, r);
     }
-    out_rec[i] = make_double2(bk, __longlong_as_double((long long)bj));   // deferred: the best so far, the overflow kernel starts from it
+    // the result (deferred: the best so far, the overflow kernel starts from it): with source records, the matched target
+    // goes into the second half of this row's own line -- the covariance kernel and the next search read it from there
+    if (prec) prec[2 * i + 1] = make_double4(sqx, sqy, sqz, __longlong_as_double((long long)bj));
+    else out_rec[i] = make_double2(bk, __longlong_as_double((long long)bj));
     if (defer) ovf_list[atomicAdd(ovf_count, 1u)] = (uint32_t)i;
 }
 
@@ -373,7 +395,7 @@ __global__ __launch_bounds__(kWG) void search_grid_overflow_kernel(
     const double *__restrict__ qy, const double *__restrict__ qz, const double4 *__restrict__ qrec4, unsigned m,
     const uint32_t *__restrict__ ovf_count,
     uint32_t *__restrict__ ovf_count_next, const uint32_t *__restrict__ ovf_list, uint32_t *__restrict__ host_count,
-    double2 *__restrict__ out_rec)
+    double4 *__restrict__ prec, double2 *__restrict__ out_rec)
 {
     __shared__ double s_d[kWG / 64], s_k[kWG / 64];
     __shared__ uint32_t s_j[kWG / 64];
@@ -389,7 +411,7 @@ __global__ __launch_bounds__(kWG) void search_grid_overflow_kernel(
         const double amax = __builtin_fmax(__builtin_fmax(__builtin_fabs(ax), __builtin_fabs(ay)), __builtin_fabs(az));
         double bk = INFINITY, dmin = INFINITY;
         uint32_t bj = 0xFFFFFFFFu;
-        const uint32_t js = (uint32_t)__double_as_longlong(out_rec[i].y);
+        const uint32_t js = (uint32_t)__double_as_longlong(prec ? prec[2 * i + 1].w : out_rec[i].y);
         if (js < m) {
             const double d = seed_d2(ax, ay, az, js, qx, qy, qz, qrec4);
             if (d < INFINITY) {
@@ -429,7 +451,17 @@ __global__ __launch_bounds__(kWG) void search_grid_overflow_kernel(
             if (b.all || b.B > edge) break;
             r = next_radius(edge, r);
         }
-        if (threadIdx.x == 0) out_rec[i] = make_double2(bk, __longlong_as_double((long long)bj));
+        if (threadIdx.x == 0) {
+            if (prec) {
+                double4 v = make_double4(0.0, 0.0, 0.0, 0.0);
+                if (bj < m) v = qrec4 ? qrec4[bj] : make_double4(qx[bj], qy[bj], qz[bj], 0.0);
+                prec[2 * i + 1] = make_double4(v.x, v.y, v.z, __longlong_as_double((long long)bj));
+            } else {
+                out_rec[i] = make_double2(bk, __longlong_as_double((long long)bj));
+            }
+        }
+        __syncthreads();   // prec[2i+1] / out_rec[i] may be read again if the queue lists the row twice (it does not), and
+                           // the shared scratch is reused by the next queued row
     }
 }
 
@@ -638,7 +670,7 @@ hipError_t search_grid(hipStream_t s, Soa3 P, size_t n, const double *pc, const 
     if (e != hipSuccess || !sc) return e;
     size_t wgs = n < 2048 ? n : 2048;
     search_grid_overflow_kernel<<<(unsigned)wgs, kWG, 0, s>>>(P.x, P.y, P.z, pc, g.d, g.start, g.rec, Qz.x, Qz.y, Qz.z, Qz.rec,
-                                                             (unsigned)m, cnt, cnt_next, sc->list, sc->host_count, out_rec);
+                                                             (unsigned)m, cnt, cnt_next, sc->list, sc->host_count, P.rec, out_rec);
     sc->parity ^= 1;
     return hipGetLastError();
 }

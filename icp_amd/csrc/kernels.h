@@ -93,7 +93,8 @@ hipError_t grid_scratch_alloc(size_t n, GridScratch *sc);
 void grid_scratch_free(GridScratch *sc);
 // order: optional processing order of the source rows (grid_order), a permutation of [0, n); results do not depend on it.
 // sc == nullptr: every lane finishes its own point, however large its box.
-// out_rec: one {key, idx as an integer bit pattern} record per source row i < n (merge_cov's grid_rec).
+// out_rec: one {key, idx as an integer bit pattern} record per source row i < n (merge_cov's grid_rec) -- written only
+// when P.rec is not set; with P.rec the result goes into P.rec[2i+1] = {matched target's coordinates, idx}.
 // P.rec, when set, holds TWO records per source row: {x, y, z, previous idx (bit pattern)} and {coordinates of that
 // target, unused} -- everything a lane needs of its row in one 64-byte line (kept current by apply and merge_cov).
 hipError_t search_grid(hipStream_t s, Soa3 P, size_t n, const double *pc, const Grid &g, Soa3 Qz, size_t m,
@@ -105,8 +106,9 @@ hipError_t grid_order(hipStream_t s, Soa3 P, size_t n, uint32_t *order);
 // Merge the splits (lowest index among equal keys), write idx[n], and reduce q (x) p per 1024-row chunk
 // into partial[chunk][12].
 hipError_t merge_cov(hipStream_t s, Soa3 P, size_t n, size_t n_pad, const double *pc, Soa3 Qz, size_t m,
-                     int q_splits, const double *keys, const uint32_t *idxs, const double2 *grid_rec, uint32_t *idx_out,
-                     double reject_d2, double *partial);
+                     int q_splits, const double *keys, const uint32_t *idxs, const double2 *grid_rec, bool result_in_rec,
+                     uint32_t *idx_out, double reject_d2, double *partial);
+// result_in_rec: search_grid ran with P.rec set and left {matched target, idx} in P.rec[2i+1]; nothing is gathered.
 // grid_rec != nullptr: the (key, idx) records of search_grid instead of keys / idxs (q_splits is then 1).
 // P.rec != nullptr: the matched target's coordinates are stored in P.rec[2i+1] (next iteration's seed).
 // reject_d2: pairs farther apart than this (squared, the oracle's un-fused d^2) get weight 0 in the sums; +inf = none.

@@ -532,7 +532,8 @@ __global__ __launch_bounds__(kWG) void cov_kernel(const double *__restrict__ px,
                                                   int q_splits, const double *__restrict__ keys,
                                                   const uint32_t *__restrict__ idxs, const double2 *__restrict__ grid_rec,
                                                   const uint32_t *__restrict__ idx_in, uint32_t *__restrict__ idx_out,
-                                                  double4 *__restrict__ prec, double reject_d2, double *__restrict__ partial)
+                                                  double4 *__restrict__ prec, bool result_in_prec, double reject_d2,
+                                                  double *__restrict__ partial)
 {
     __shared__ double smem[4 * kCovW];
     const double c0 = pc[0], c1 = pc[1], c2 = pc[2];
@@ -545,7 +546,15 @@ __global__ __launch_bounds__(kWG) void cov_kernel(const double *__restrict__ px,
         const size_t i = base + (size_t)k * kWG;
         if (i < n) {
             uint32_t j;
-            if (MERGE && grid_rec) {
+            double q0 = 0.0, q1 = 0.0, q2 = 0.0;
+            bool have_q = false;
+            if (MERGE && result_in_prec) {   // the grid search left {matched target, idx} in the row's own record
+                const double4 v = prec[2 * i + 1];
+                j = (uint32_t)__double_as_longlong(v.w);
+                q0 = v.x; q1 = v.y; q2 = v.z;
+                have_q = true;
+                idx_out[i] = j;
+            } else if (MERGE && grid_rec) {
                 j = (uint32_t)__double_as_longlong(grid_rec[i].y);
                 idx_out[i] = j;
             } else if (MERGE) {
@@ -565,16 +574,17 @@ __global__ __launch_bounds__(kWG) void cov_kernel(const double *__restrict__ px,
             }
             if (j < m) {
                 const double p0 = px[i] - c0, p1 = py[i] - c1, p2 = pz[i] - c2;
-                double q0, q1, q2;
-                if (qrec4) {   // one 32-byte record per gathered target
-                    const double4 v = qrec4[j];
-                    q0 = v.x; q1 = v.y; q2 = v.z;
-                } else {
-                    q0 = qx[j]; q1 = qy[j]; q2 = qz[j];
+                if (!have_q) {
+                    if (qrec4) {   // one 32-byte record per gathered target
+                        const double4 v = qrec4[j];
+                        q0 = v.x; q1 = v.y; q2 = v.z;
+                    } else {
+                        q0 = qx[j]; q1 = qy[j]; q2 = qz[j];
+                    }
+                    if (MERGE && prec) prec[2 * i + 1] = make_double4(q0, q1, q2, 0.0);   // the next search's seed, next to its point
                 }
                 // the weight hook of compute_cross_variance (src/cpu/icp.cpp:108-131: weight = kernel(p - q), a constant 1
                 // there) as a hard threshold on the pair's distance: weight 1 up to reject_d2 (+inf = the reference), else 0
-                if (MERGE && prec) prec[2 * i + 1] = make_double4(q0, q1, q2, 0.0);   // the next search's seed, next to its point
                 const double d = d2_exact(p0, p1, p2, q0, q1, q2);
                 if (d <= reject_d2) {
                     acc[0] += q0 * p0; acc[1] += q0 * p1; acc[2] += q0 * p2;
@@ -1260,12 +1270,13 @@ hipError_t search_f32(hipStream_t s, int ppl, int cb, Soa3 P, size_t n_pad, cons
 }
 
 hipError_t merge_cov(hipStream_t s, Soa3 P, size_t n, size_t n_pad, const double *pc, Soa3 Qz, size_t m, int q_splits,
-                     const double *keys, const uint32_t *idxs, const double2 *grid_rec, uint32_t *idx_out, double reject_d2,
-                     double *partial)
+                     const double *keys, const uint32_t *idxs, const double2 *grid_rec, bool result_in_rec, uint32_t *idx_out,
+                     double reject_d2, double *partial)
 {
     if (n == 0) return hipSuccess;
+    if (result_in_rec && !P.rec) return hipErrorInvalidValue;
     cov_kernel<true><<<blocks_for(n, kChunk), kWG, 0, s>>>(P.x, P.y, P.z, n, n_pad, pc, Qz.x, Qz.y, Qz.z, Qz.rec, m, q_splits, keys,
-                                                           idxs, grid_rec, nullptr, idx_out, P.rec, reject_d2, partial);
+                                                           idxs, grid_rec, nullptr, idx_out, P.rec, result_in_rec, reject_d2, partial);
     return hipGetLastError();
 }
 
@@ -1274,7 +1285,7 @@ hipError_t cov_from_idx(hipStream_t s, Soa3 P, size_t n, const double *pc, Soa3 
 {
     if (n == 0) return hipSuccess;
     cov_kernel<false><<<blocks_for(n, kChunk), kWG, 0, s>>>(P.x, P.y, P.z, n, 0, pc, Qz.x, Qz.y, Qz.z, Qz.rec, m, 1, nullptr, nullptr,
-                                                            nullptr, idx, nullptr, nullptr, INFINITY, partial);
+                                                            nullptr, idx, nullptr, nullptr, false, INFINITY, partial);
     return hipGetLastError();
 }
 
