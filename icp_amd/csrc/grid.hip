@@ -626,7 +626,7 @@ static double env_per_cell(const char *name, double dflt)
 hipError_t grid_build(hipStream_t s, Soa3 Qz, size_t m, Grid *g)
 {
     const char *rf = getenv("ICP_AMD_GRID_REFINE");
-    return grid_sort(s, Qz, m, env_per_cell("ICP_AMD_GRID_PER_CELL", 4.0), true, !(rf && atoi(rf) == 0), g);
+    return grid_sort(s, Qz, m, env_per_cell("ICP_AMD_GRID_PER_CELL", 2.0), true, !(rf && atoi(rf) == 0), g);
 }
 
 __global__ __launch_bounds__(kWG) void iota_kernel(uint32_t *out, size_t n)
