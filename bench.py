@@ -54,7 +54,8 @@ def roofline(variant, n_local, M, avg_ms, launches):
             "flops_per_pair": FLOPS_PER_PAIR, "pairs_per_launch": float(n_local) * float(M), "avg_launch_ms": avg_ms,
             "launches": launches, "traffic": None, "variant": variant, "instruction_mix": mix,
             "note": ("fp32 vector peak 157.3 TFLOP/s" if f32 else
-                     "un-fused fp64 VALU peak 39.3 TFLOP/s = one flop per op (FMA-counted datasheet peak: 78.6)")}
+                     "un-fused fp64 VALU peak 39.3 TFLOP/s = one flop per op (FMA-counted datasheet peak: 78.6); the FMA "
+                     "variant issues 7.08 instructions for the 8 algorithmic flops, so its frac can pass 1")}
 
 
 def fp64_variants(P, Q, device, steps=3):
