@@ -321,6 +321,7 @@ static int read_npy(const char *path, double **out, size_t *nblines, size_t *nbc
         if (dims.empty() || dims.size() > 2) { rc = io_fail(ICP_AMD_EIO, ".npy cloud must be 1- or 2-dimensional"); break; }
         rows = dims[0];
         cols = dims.size() == 2 ? dims[1] : 1;
+        if (cols != 0 && rows > ((size_t)-1) / sizeof(double) / cols) { rc = io_fail(ICP_AMD_EIO, ".npy shape overflows"); break; }
         const size_t bytes = rows * cols * sizeof(double);
         double *r = (double *)malloc(bytes ? bytes : 1);
         if (!r) { rc = io_fail(ICP_AMD_ENOMEM, "Alloc error !"); break; }
