@@ -15,6 +15,8 @@
 
 #include <limits>
 #include <new>
+#include <string>
+#include <thread>
 #include <vector>
 
 using namespace icpk;
@@ -881,8 +883,23 @@ extern "C" int icp_amd_run_multi(const double *P, size_t n, const double *Q, siz
     for (int g = 0; g < G; ++g) {
         lo[g] = (size_t)g * rpr < n ? (size_t)g * rpr : n;
         cnt[g] = n - lo[g] < rpr ? n - lo[g] : rpr;
-        RCCHK(icp_amd_set_target(r.eng[g], Q, m));
-        RCCHK(icp_amd_set_source(r.eng[g], P + lo[g] * 3, cnt[g]));
+    }
+    {   // the per-device set-up (uploads, centring, records, grid build: milliseconds each, with host waits) runs on one
+        // host thread per device; the error text is thread-local, so it is carried back by hand
+        std::vector<int> rcs(G, ICP_AMD_OK);
+        std::vector<std::string> errs(G);
+        std::vector<std::thread> pool;
+        auto setup = [&](int g) {
+            int rc = icp_amd_set_target(r.eng[g], Q, m);
+            if (rc == ICP_AMD_OK) rc = icp_amd_set_source(r.eng[g], P + lo[g] * 3, cnt[g]);
+            rcs[g] = rc;
+            if (rc != ICP_AMD_OK) errs[g] = icp_amd_last_error();
+        };
+        for (int g = 1; g < G; ++g) pool.emplace_back(setup, g);
+        setup(0);
+        for (std::thread &t : pool) t.join();
+        for (int g = 0; g < G; ++g)
+            if (rcs[g] != ICP_AMD_OK) return fail(rcs[g], "%s", errs[g].c_str());
     }
     for (int g = 0; g < G; ++g) RCCHK(icp_amd_step_begin(r.eng[g]));
     RCCHK(all_gather_partials(r, r.cen, cpr * kCenW));
