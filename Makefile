@@ -8,7 +8,10 @@ LIB      := icp_amd/libicp_amd.so
 
 all: $(LIB) bin/GPUICP oracle
 
-$(CSRC)/kernels.o: $(CSRC)/kernels.hip $(CSRC)/kernels.h $(CSRC)/exact.h
+$(CSRC)/kernels.o: $(CSRC)/kernels.hip $(CSRC)/kernels.h $(CSRC)/exact.h $(CSRC)/search_common.h
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+$(CSRC)/search_mfma.o: $(CSRC)/search_mfma.hip $(CSRC)/kernels.h $(CSRC)/exact.h $(CSRC)/search_common.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
 $(CSRC)/grid.o: $(CSRC)/grid.hip $(CSRC)/kernels.h $(CSRC)/exact.h
@@ -20,7 +23,7 @@ $(CSRC)/engine.o: $(CSRC)/engine.hip $(CSRC)/kernels.h include/icp_amd.h
 $(CSRC)/hostio.o: $(CSRC)/hostio.cpp include/icp_amd.h
 	$(CXX) -O2 -std=c++17 -fPIC -ffp-contract=off -Wall -Wextra -c $< -o $@
 
-$(LIB): $(CSRC)/kernels.o $(CSRC)/grid.o $(CSRC)/engine.o $(CSRC)/hostio.o
+$(LIB): $(CSRC)/kernels.o $(CSRC)/search_mfma.o $(CSRC)/grid.o $(CSRC)/engine.o $(CSRC)/hostio.o
 	$(HIPCC) --offload-arch=$(ARCH) -shared -o $@ $^ -ldl
 
 bin/GPUICP: $(CSRC)/gpuicp_main.cpp $(LIB) include/icp_amd.h

@@ -105,6 +105,7 @@ struct icp_amd_engine {
     unsigned long long *qmax2_dev = nullptr;
     double qmax = 0.0;          // sqrt(max |q|^2) of the centred target
     bool f32_ok = false;        // the fp32 error bound is meaningful for this target's range
+    int mfma_g = 0;             // F32 on the matrix pipe: 32-row source groups per wave (0: packed-VALU kernel)
     Grid grid;                  // uniform grid over Qz (search variant GRID); built on first use per target
     bool grid_built = false;
     uint32_t *order = nullptr;  // n_pad: source rows in spatial order (GRID), valid when order_ok
@@ -296,6 +297,16 @@ static int requested_variant(const icp_amd_engine *e)
     if (sv && !strcmp(sv, "auto")) variant = 0;
     return variant;
 }
+// ICP_AMD_MFMA=2|4|8 runs F32's pre-filter on the matrix pipe (search_mfma.hip; the value is the number of 32-row source
+// groups per wave).  Off by default: on gfx950 the fp32 MFMA does not co-execute with VALU instructions
+// (SQ_VALU_MFMA_COEXEC_CYCLES = 0), so the min/event work is added to the 64 cycles per MFMA instead of hiding behind
+// them -- 1M x 1M: 74.2 ms against 67.3 ms for the packed-VALU kernel (profiles/r1_v8_mfma_experiment.txt).
+static int mfma_groups()
+{
+    const int v = env_int("ICP_AMD_MFMA", 0);
+    return (v == 2 || v == 4 || v == 8) ? v : 0;
+}
+
 // AUTO searches on the grid from this many targets on: the grid saves 18 us per iteration at 1000 targets (36 at 2000)
 // and costs about 250 us more to set up (tools/tiny_probe.py), so it pays from roughly 15 iterations on here.
 static const size_t kAutoGridMinTargets = 1024;
@@ -336,7 +347,8 @@ static void choose_geometry(icp_amd_engine *e)
     size_t want = (size_t)(sqrt(pairs) / 40.0 * ((double)cus / 256.0));
     if (want < 2 * cus) want = 2 * cus;
     if (want > 64 * cus) want = 64 * cus;
-    const size_t xblocks = e->n_pad / ((size_t)kWG * ppl);
+    e->mfma_g = f32 ? mfma_groups() : 0;
+    const size_t xblocks = e->n_pad / (e->mfma_g ? (size_t)search_mfma_rows_per_workgroup(e->mfma_g) : (size_t)kWG * ppl);
     size_t splits = (want + xblocks - 1) / xblocks;
     if (splits > 1024) splits = 1024;
     if (e->opt.q_splits > 0) splits = (size_t)e->opt.q_splits;
@@ -543,6 +555,9 @@ extern "C" int icp_amd_step_search(icp_amd_engine *e)
         if (grid)
             HIPCHK(search_grid(e->stream, e->P, e->n, e->pc, e->grid, e->Qz, e->m, seed ? e->idx : nullptr,
                                e->order_ok ? e->order : nullptr, &e->gscratch, e->grid_out));
+        else if (e->variant == kF32 && e->mfma_g)
+            HIPCHK(search_mfma(e->stream, e->mfma_g, e->P, e->n_pad, e->pc, e->Qz, e->qrec, e->qmax, e->m, e->m_pad, splits,
+                               seed ? e->idx : nullptr, e->keys, e->idxs));
         else if (e->variant == kF32)
             HIPCHK(search_f32(e->stream, e->ppl, e->cb, e->P, e->n_pad, e->pc, e->Qz, e->qrec, e->qmax, e->m, e->m_pad, splits,
                               seed ? e->idx : nullptr, e->keys, e->idxs));
@@ -717,10 +732,11 @@ extern "C" int icp_amd_kernel_ms(icp_amd_engine *e, double *avg_ms, double *tota
 extern "C" int icp_amd_search_geometry(icp_amd_engine *e, int *ppl, int *q_splits, int *workgroups, int *variant)
 {
     if (!e || !e->have_source) return fail(ICP_AMD_ESTATE, "icp_amd_search_geometry: no source cloud");
-    if (ppl) *ppl = e->use_grid ? 1 : e->ppl;
+    // source rows per workgroup: 256 lanes x ppl, or 128 x groups when the fp32 filter runs on the matrix pipe (two lanes per row)
+    const size_t rows_wg = e->mfma_g ? (size_t)search_mfma_rows_per_workgroup(e->mfma_g) : (size_t)kWG * e->ppl;
+    if (ppl) *ppl = e->use_grid ? 1 : (int)(rows_wg / kWG ? rows_wg / kWG : 1);
     if (q_splits) *q_splits = e->use_grid ? 1 : e->q_splits;
-    if (workgroups)
-        *workgroups = e->use_grid ? (int)((e->n + kWG - 1) / kWG) : (int)(e->n_pad / ((size_t)kWG * e->ppl)) * e->q_splits;
+    if (workgroups) *workgroups = e->use_grid ? (int)((e->n + kWG - 1) / kWG) : (int)(e->n_pad / rows_wg) * e->q_splits;
     if (variant) *variant = e->use_grid ? (int)kGrid : e->variant;
     return ICP_AMD_OK;
 }
@@ -1128,8 +1144,12 @@ extern "C" int icp_amd_correspondences(const double *P, size_t n, const double P
         double qmax2;
         memcpy(&qmax2, &bits, sizeof qmax2);
         if ((qmax2 == qmax2) && qmax2 > 1e-30 && qmax2 < 1e30) {
-            HIPCHK(search_f32(s, ppl, cb, dP, n_pad, pc.as<double>(), dQ, qrec.p, sqrt(qmax2), m, m_pad, q_splits, nullptr,
-                              keys.as<double>(), idxs.as<uint32_t>()));
+            if (mfma_groups())
+                HIPCHK(search_mfma(s, mfma_groups(), dP, n_pad, pc.as<double>(), dQ, qrec.p, sqrt(qmax2), m, m_pad, q_splits, nullptr,
+                                   keys.as<double>(), idxs.as<uint32_t>()));
+            else
+                HIPCHK(search_f32(s, ppl, cb, dP, n_pad, pc.as<double>(), dQ, qrec.p, sqrt(qmax2), m, m_pad, q_splits, nullptr,
+                                  keys.as<double>(), idxs.as<uint32_t>()));
         } else {   // range outside the fp32 bound's domain: same degradation as the engine
             if (ppl == 8) ppl = 4;
             HIPCHK(search(s, kFma, ppl, cb, dP, n_pad, pc.as<double>(), dQ, m, m_pad, q_splits, nullptr, keys.as<double>(),

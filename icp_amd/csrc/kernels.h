@@ -57,6 +57,13 @@ hipError_t search_f32(hipStream_t s, int ppl, int cb, Soa3 P, size_t n_pad, cons
                       double qmax, size_t m, size_t m_pad, int q_splits, const uint32_t *idx_prev, double *out_key,
                       uint32_t *out_idx);
 
+// The same pre-filter on the matrix pipe (search_mfma.hip): two v_mfma_f32_32x32x2_f32 per 32 targets x 32 source rows.
+// Same records, same results as search_f32; groups in {2,4,8} = 32-row source groups per wave, a workgroup covers
+// search_mfma_rows_per_workgroup(groups) = 128 * groups source rows.
+int search_mfma_rows_per_workgroup(int groups);
+hipError_t search_mfma(hipStream_t s, int groups, Soa3 P, size_t n_pad, const double *pc, Soa3 Qz, const void *qrec, double qmax,
+                       size_t m, size_t m_pad, int q_splits, const uint32_t *idx_prev, double *out_key, uint32_t *out_idx);
+
 // Uniform grid over the centred target cloud (grid.hip): same correspondences as the brute-force kernels, found by
 // evaluating only the targets in the cells a query's search box touches.
 struct GridDesc {

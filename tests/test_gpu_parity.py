@@ -90,6 +90,40 @@ def test_f32_prefilter_whole_loop_and_scale_robustness(monkeypatch):
         assert np.array_equal(a, b), (scale, shift)
 
 
+@pytest.mark.parametrize("groups", ["2", "4", "8"])
+def test_matrix_pipe_prefilter_is_only_a_filter(monkeypatch, groups):
+    """ICP_AMD_MFMA=2|4|8: the same fp32 filter on v_mfma_f32_32x32x2_f32 (search_mfma.hip, opt-in).  Same indices as the
+    oracle on the golden cases (whole loop, seeded iterations included), on the adversarial ties (stage level, several
+    splits) and across scales / offsets, where its looser error bound only means more slow-path visits."""
+    monkeypatch.setenv("ICP_AMD_SEARCH", "f32")
+    monkeypatch.setenv("ICP_AMD_MFMA", groups)
+    for name in ("cow_tr1", "syn3k_4k", "lattice", "c1_30pts"):
+        g = golden(name)
+        P_out, tr = icp_amd.icp_gpu_optimized(g["P"], g["Q"], int(g["iters"]), trace=True)
+        assert np.array_equal(tr["idx"], g["idx"]), name
+        assert relerr(P_out, g["P_out"]) < TOL
+    g = golden("ties_corr")
+    for splits in (1, 2, 3):
+        idx = icp_amd.correspondences(g["Pz"], np.zeros(3), g["Qz"], search="f32", q_splits=splits)
+        assert np.array_equal(idx, g["idx"]), splits
+    P, Q = synth.make_pair(5000, 6000, seed=78)
+    for scale, shift in ((1.0, 0.0), (1e-6, 0.0), (1e6, 0.0), (1.0, 1e4), (1e-3, 50.0), (1e20, 0.0)):
+        Ps, Qs = P * scale + shift, Q * scale + shift
+        b, tb = icp_amd.icp_gpu_optimized(Ps, Qs, 2, trace=True)
+        monkeypatch.setenv("ICP_AMD_SEARCH", "exact")
+        a, ta = icp_amd.icp_gpu_optimized(Ps, Qs, 2, trace=True)
+        monkeypatch.setenv("ICP_AMD_SEARCH", "f32")
+        assert np.array_equal(ta["idx"], tb["idx"]), (scale, shift)
+        assert np.array_equal(a, b), (scale, shift)
+    # sources far outside the range of the fp32 bound (the lane then takes the exact path on every block)
+    Pf = P.copy()
+    Pf[::7] *= 1e18
+    b, tb = icp_amd.icp_gpu_optimized(Pf, Q, 1, trace=True)
+    monkeypatch.setenv("ICP_AMD_SEARCH", "exact")
+    a, ta = icp_amd.icp_gpu_optimized(Pf, Q, 1, trace=True)
+    assert np.array_equal(ta["idx"], tb["idx"])
+
+
 @pytest.mark.parametrize("method", ["-loop", "-shared", "-shared-loop", "-batch"])
 def test_all_method_flags_give_the_same_result(method):
     g = golden("syn256")
