@@ -34,8 +34,35 @@ static int io_fail(int code, const std::string &msg) { return icp_amd_fail_(code
 // consumes nothing); the column count is the field count of the first line; fields are separated by ','
 // with empty fields skipped (strtok semantics); a field counts as a number as soon as strtod consumes a
 // prefix of it; a non-numeric field after the first line -- including the field of a trailing blank line --
-// is the error "Not a valid double !".  Unlike the reference, ragged files are rejected instead of
-// producing an array whose size disagrees with nblines x nbcols.
+// is the error "Not a valid double !".  Two quirks of readCSV are kept as well, because they decide what a caller gets
+// from a well-formed file (tools/fuzz_csv.py compares against the reference's own reader, file by file):
+//  * a file WITHOUT a header line and with two or more lines loses its last row: the reference stores the second line as
+//    the "header" text once the first line turned out to be numeric (csv.cpp:113-114,128-129) and then counts one line
+//    less (csv.cpp:147-148).  nblines, the values and the header text returned here are the reference's;
+//  * a file without a single number (empty, or a header only) is the error "Alloc error (realloc) !" (csv.cpp:151-156,
+//    realloc to size 0).
+// Unlike the reference, files it would turn into an array whose size disagrees with nblines x nbcols (ragged rows, a
+// first line that mixes numbers and text) are rejected.
+static int finish_csv(std::vector<double> &&vals, size_t lines, size_t cols, bool has_header, const std::string &second_line,
+                      double **out, size_t *nblines, size_t *nbcols, char *header, size_t header_cap)
+{
+    if (vals.empty()) return io_fail(ICP_AMD_EIO, "Alloc error (realloc) !");
+    size_t rows = has_header ? lines - 1 : lines;
+    if (vals.size() != rows * cols) return io_fail(ICP_AMD_EIO, "CSV size mismatch");
+    if (!has_header && lines >= 2) {   // the reference's header bookkeeping: the second line is reported as the header, the last row is lost
+        --rows;
+        vals.resize(rows * cols);
+        if (header && header_cap) snprintf(header, header_cap, "%s", second_line.c_str());
+    }
+    double *r = (double *)malloc(vals.size() * sizeof(double));
+    if (!r) return io_fail(ICP_AMD_ENOMEM, "Alloc error !");
+    memcpy(r, vals.data(), vals.size() * sizeof(double));
+    *out = r;
+    *nblines = rows;
+    *nbcols = cols;
+    return ICP_AMD_OK;
+}
+
 extern "C" int icp_amd_read_csv(const char *path, double **out, size_t *nblines, size_t *nbcols, char *header, size_t header_cap)
 {
     if (!path || !out || !nblines || !nbcols) return io_fail(ICP_AMD_EINVAL, "icp_amd_read_csv: NULL argument");
@@ -48,11 +75,13 @@ extern "C" int icp_amd_read_csv(const char *path, double **out, size_t *nblines,
     char *line = nullptr;
     size_t cap = 0, lines = 0, cols = 0;
     bool has_header = false;
+    std::string second;
     int rc = ICP_AMD_OK;
     ssize_t len;
     while (rc == ICP_AMD_OK && (len = getline(&line, &cap, f)) != -1) {
         size_t fields = 0, numeric = 0;
         const std::string raw(line, (size_t)len);
+        if (lines == 1) second = raw;
         char *cur = line;
         const bool first = (lines == 0);
         while (*cur) {
@@ -93,15 +122,7 @@ extern "C" int icp_amd_read_csv(const char *path, double **out, size_t *nblines,
     free(line);
     fclose(f);
     if (rc != ICP_AMD_OK) return rc;
-    const size_t rows = has_header ? lines - 1 : lines;
-    if (vals.size() != rows * cols) return io_fail(ICP_AMD_EIO, "CSV size mismatch");
-    double *r = (double *)malloc((vals.empty() ? 1 : vals.size()) * sizeof(double));
-    if (!r) return io_fail(ICP_AMD_ENOMEM, "Alloc error !");
-    if (!vals.empty()) memcpy(r, vals.data(), vals.size() * sizeof(double));
-    *out = r;
-    *nblines = rows;
-    *nbcols = cols;
-    return ICP_AMD_OK;
+    return finish_csv(std::move(vals), lines, cols, has_header, second, out, nblines, nbcols, header, header_cap);
 }
 
 extern "C" void icp_amd_free(void *p) { free(p); }
@@ -177,18 +198,6 @@ int read_whole(const char *path, std::vector<char> &buf)
     return ICP_AMD_OK;
 }
 
-int finish(std::vector<double> &&vals, size_t rows, size_t cols, double **out, size_t *nblines, size_t *nbcols)
-{
-    if (vals.size() != rows * cols) return io_fail(ICP_AMD_EIO, "CSV size mismatch");
-    double *r = (double *)malloc((vals.empty() ? 1 : vals.size()) * sizeof(double));
-    if (!r) return io_fail(ICP_AMD_ENOMEM, "Alloc error !");
-    if (!vals.empty()) memcpy(r, vals.data(), vals.size() * sizeof(double));
-    *out = r;
-    *nblines = rows;
-    *nbcols = cols;
-    return ICP_AMD_OK;
-}
-
 bool ends_with(const char *s, const char *suffix)
 {
     const size_t n = strlen(s), k = strlen(suffix);
@@ -212,7 +221,7 @@ extern "C" int icp_amd_read_csv_mt(const char *path, int threads, double **out, 
     const char *b = buf.data(), *e = b + buf.size() - 1;
     // getline() semantics end at an embedded NUL as far as strtok/strtod are concerned; such files take the serial path
     if (memchr(b, '\0', (size_t)(e - b))) return icp_amd_read_csv(path, out, nblines, nbcols, header, header_cap);
-    if (b == e) return finish({}, 0, 0, out, nblines, nbcols);
+    if (b == e) return io_fail(ICP_AMD_EIO, "Alloc error (realloc) !");
     // first line: header detection and the column count
     const char *nl = (const char *)memchr(b, '\n', (size_t)(e - b));
     const char *le = nl ? nl + 1 : e;
@@ -256,7 +265,12 @@ extern "C" int icp_amd_read_csv_mt(const char *path, int threads, double **out, 
     vals.reserve(total);
     vals.insert(vals.end(), head.begin(), head.end());
     for (ChunkResult &c : res) vals.insert(vals.end(), c.vals.begin(), c.vals.end());
-    return finish(std::move(vals), has_header ? lines - 1 : lines, cols, out, nblines, nbcols);
+    std::string second;
+    if (!has_header && le < e) {
+        const char *nl2 = (const char *)memchr(le, '\n', (size_t)(e - le));
+        second.assign(le, nl2 ? nl2 + 1 : e);
+    }
+    return finish_csv(std::move(vals), lines, cols, has_header, second, out, nblines, nbcols, header, header_cap);
 }
 
 // Raw little-endian fp64, row-major, `cols` columns (the GPUICP clouds have 3).

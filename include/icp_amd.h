@@ -183,7 +183,11 @@ int icp_amd_apply(const double *P_xyz, size_t n, const double R[9], const double
 
 /* ---- host I/O kept from the reference */
 /* readCSV (include/libCSV/csv.hpp:33, src/libCSV/csv.cpp:94-158): optional header line, strtod parsing.
- * *out is malloc'd (free with icp_amd_free). header: optional buffer for the header line. */
+ * *out is malloc'd (free with icp_amd_free). header: optional buffer for the header line.
+ * Row counts are the reference's, quirks included: a file WITHOUT a header line and with two or more lines comes back one
+ * row short (csv.cpp:113-114,147-148 take its second line for the header text), and a file without any number is an
+ * error (csv.cpp:151-156).  Files the reference would turn into an array that disagrees with nblines x nbcols (ragged
+ * rows, a first line mixing numbers and text) are rejected with an error instead. */
 int    icp_amd_read_csv(const char *path, double **out, size_t *nblines, size_t *nbcols, char *header, size_t header_cap);
 void   icp_amd_free(void *p);
 /* CPUMatrix::write_in_file / operator<< (src/libalg/CPUMatrix.cpp:81-94,323-327) */

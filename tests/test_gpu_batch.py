@@ -101,6 +101,7 @@ def test_cli_batch_argument(tmp_path):
     P, Q = synth.make_batch(3, 200)
     for name, A in (("P.txt", P), ("Q.txt", Q)):
         with open(tmp_path / name, "w") as f:
+            f.write("Points_0,Points_1,Points_2\n")   # without a header line the reference's reader drops the last row
             for r in A.reshape(-1, 3):
                 f.write("%.17g,%.17g,%.17g\n" % tuple(r))
     exe = os.path.join(ROOT, "bin", "GPUICP")
