@@ -1,10 +1,14 @@
 """CPU: pin the oracle (oracle/icp_oracle.c, our restatement) against golden vectors produced by the
 unmodified reference sources (tests/golden/make_golden.py).  Integer results bit-exact; Pc / cov
 bit-exact (same summation order); R, t, P_out within 1e-12 (own Jacobi SVD vs LAPACK dgesvd)."""
+import os
+import sys
+
 import numpy as np
 import pytest
 
 from conftest import ICP_CASES, golden, relerr, relerr_t
+from conftest import ROOT
 from oracle import pyoracle as orc
 
 NTHREADS = 8
@@ -98,3 +102,14 @@ def test_svd3_degenerate_and_random():
             assert relerr(U @ VT, Un @ VTn) < 1e-9
     U, S, VT = orc.svd3(np.zeros((3, 3)))
     assert np.array_equal(U @ VT, np.eye(3))
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "ref_trace")), reason="needs oracle/_ref (build container)")
+def test_oracle_against_the_reference_on_random_adversarial_clouds():
+    """tools/fuzz_oracle.py, short: the oracle against the unmodified reference (oracle/_ref/ref_trace) beyond the committed
+    golden vectors -- lattices with exact ties, duplicates, clusters, few-ulp near-ties, wild scales, coplanar / collinear
+    clouds, N != M.  Centroid, indices, covariance and the applied transform bit-exact, stage by stage."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import fuzz_oracle
+    cases, bad = fuzz_oracle.run(120.0, seed=3, verbose=False, max_cases=150)
+    assert cases == 150 and bad == []
