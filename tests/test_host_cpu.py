@@ -171,6 +171,16 @@ def test_write_cloud_and_report_format(tmp_path):
         icp_amd.euclidian_distance(g["Q"], g["P_out"][:5])
 
 
+@pytest.mark.skipif(not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "CPUICP")), reason="needs oracle/_ref (build container)")
+def test_writer_and_report_against_the_reference_executable():
+    """tools/fuzz_writer.py, short: `point_cloud_result` and the "Squared actual mean diff" line of the reference's own
+    CPUICP (unmodified main.cpp) are reproduced byte for byte from the doubles it held, across scales 1e-8 .. 1e8."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import fuzz_writer
+    compared, bad = fuzz_writer.run(40, seed=5, verbose=False)
+    assert compared >= 30 and bad == []
+
+
 def test_cli_argument_errors():
     exe = os.path.join(ROOT, "bin", "GPUICP")
     r = subprocess.run([exe, "a", "b"], capture_output=True, text=True)
