@@ -282,6 +282,50 @@ def test_cli_matches_reference_output(tmp_path):
     assert r.returncode != 0 and "Invalid method, must be: -shared|-loop|-shared-loop|-batch" in r.stderr
 
 
+@pytest.mark.skipif(not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "CPUICP")), reason="needs the built oracle/_ref/CPUICP")
+def test_cli_against_the_reference_executable_on_random_pairs(tmp_path):
+    """The two executables side by side on inputs no fixture holds: oracle/_ref/CPUICP (the reference's src/cpu/main.cpp,
+    compiled unmodified; CPU) and bin/GPUICP (this library; GPU) read the same CSV files.  The result files agree -- same
+    first line, every value within the 6 digits the format carries -- and so does the printed report.  One pair is
+    header-less: both programs lose its last row (csv.cpp:147-148)."""
+    exe, ref = os.path.join(ROOT, "bin", "GPUICP"), os.path.join(ROOT, "oracle", "_ref", "CPUICP")
+    rng = np.random.RandomState(21)
+    def parse(path):
+        lines = open(path).read().split("\n")
+        return lines[0], np.array([[float(v) for v in ln.split()] for ln in lines[1:] if ln.strip()])
+    for case in range(10):
+        n = int(rng.randint(40, 1500))
+        scale = 10.0 ** rng.uniform(-3, 3)
+        Q = rng.uniform(-1, 1, (n, 3)) * scale
+        a = rng.uniform(-0.4, 0.4)
+        R = np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1]])
+        P = Q[rng.permutation(n)] @ R.T + rng.uniform(-0.1, 0.1, 3) * scale + rng.standard_normal((n, 3)) * scale * 1e-3
+        header = case != 3
+        for name, A in (("P.txt", P), ("Q.txt", Q)):
+            with open(tmp_path / name, "w") as f:
+                if header:
+                    f.write("Points_0,Points_1,Points_2\n")
+                for r in A:
+                    f.write("%.17g,%.17g,%.17g\n" % tuple(r))
+        iters = int(rng.randint(1, 7))
+        outs = []
+        for cmd, sub in (([ref, "P.txt", "Q.txt", str(iters)], "r"), ([exe, "P.txt", "Q.txt", str(iters), "-shared-loop"], "g")):
+            d = tmp_path / ("%s%d" % (sub, case))
+            d.mkdir()
+            for name in ("P.txt", "Q.txt"):
+                os.link(tmp_path / name, d / name)
+            r = subprocess.run(cmd, cwd=d, capture_output=True, text=True, timeout=200)
+            assert r.returncode == 0, (case, cmd[0], r.stderr[-2000:])
+            outs.append((r.stdout.strip(), parse(d / "point_cloud_result")))
+        (line_r, (h_r, A_r)), (line_g, (h_g, A_g)) = outs
+        assert h_r == h_g == " dim0: %d dim1: 3 array: " % (n if header else n - 1), case
+        assert A_r.shape == A_g.shape
+        assert np.abs(A_r - A_g).max() <= 2e-5 * max(np.abs(A_r).max(), 1e-300), case
+        d_r, d_g = float(line_r.split(":")[1]), float(line_g.split(":")[1])
+        assert line_r.startswith("Squared actual mean diff: ") and line_g.startswith("Squared actual mean diff: ")
+        assert abs(d_r - d_g) <= 2e-5 * max(abs(d_r), 1e-12 * scale), (case, line_r, line_g)
+
+
 def test_stage_level_f32_fallback_uses_the_requested_splits():
     """Regression (found by tools/fuzz_variants.py): a target whose range defeats the fp32 bound makes the stage-level
     F32 search fall back to FMA; it must run with the same number of target splits the merge then reads."""
