@@ -32,6 +32,11 @@ def device_count():
     return int(lib().icp_amd_device_count())
 
 
+def init(device=-1):
+    """icp_amd_init: create the HIP context and load the code objects now (e.g. on another thread, beside file parsing)."""
+    check(lib().icp_amd_init(C.c_int(device)))
+
+
 def rows_per_rank(n_global, world):
     return int(lib().icp_amd_rows_per_rank(n_global, world))
 

@@ -62,6 +62,24 @@ static int require_device(int device)
     return ICP_AMD_OK;
 }
 
+static int env_int(const char *name, int dflt);
+
+// Context creation + code-object load, for callers that can overlap it with their own I/O.  One tiny launch per
+// translation unit with kernels (kernels.hip, grid.hip): HIP loads a unit's code object at its first launch.
+extern "C" int icp_amd_init(int device)
+{
+    RCCHK(require_device(device < 0 ? env_int("ICP_AMD_DEVICE", 0) : device));
+    double *buf = nullptr;
+    HIPCHK(hipMalloc(&buf, 8 * sizeof(double)));
+    hipError_t er = hipMemsetAsync(buf, 0, 8 * sizeof(double), nullptr);
+    if (er == hipSuccess) er = finalize_centroid(nullptr, buf, 1, 1.0, buf + 3);
+    if (er == hipSuccess) er = grid_warmup(nullptr);
+    if (er == hipSuccess) er = hipStreamSynchronize(nullptr);
+    (void)hipFree(buf);
+    HIPCHK(er);
+    return ICP_AMD_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // sharding arithmetic
 // ------------------------------------------------------------------------------------------------

@@ -468,6 +468,13 @@ __global__ __launch_bounds__(kWG) void search_grid_overflow_kernel(
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
+__global__ void grid_warmup_kernel() {}
+hipError_t grid_warmup(hipStream_t s)
+{
+    grid_warmup_kernel<<<1, 64, 0, s>>>();
+    return hipGetLastError();
+}
+
 void grid_free(Grid *g)
 {
     if (!g) return;

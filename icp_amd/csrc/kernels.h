@@ -66,6 +66,8 @@ hipError_t search_mfma(hipStream_t s, int groups, Soa3 P, size_t n_pad, const do
 
 // Uniform grid over the centred target cloud (grid.hip): same correspondences as the brute-force kernels, found by
 // evaluating only the targets in the cells a query's search box touches.
+// one empty launch from grid.hip: loads that translation unit's code object (icp_amd_init)
+hipError_t grid_warmup(hipStream_t s);
 struct GridDesc {
     double lo[3], hi[3];   // bounding box of the targets
     double inv[3];         // cells per unit length along each axis (0 for an axis of zero extent)

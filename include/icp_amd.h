@@ -86,6 +86,11 @@ const char *icp_amd_last_error(void);
 int         icp_amd_version(void);
 int         icp_amd_device_count(void);
 void        icp_amd_default_options(icp_amd_options *opt);
+/* Optional warm-up (no counterpart in the reference, whose first cudaMalloc pays for it): creates the HIP context on
+ * `device` (-1: ICP_AMD_DEVICE, default 0) and loads the library's code objects, about 0.15 s in a fresh process.  A
+ * caller with input files to parse can run it on another thread meanwhile, as GPUICP does; every other entry point
+ * initialises on demand. */
+int         icp_amd_init(int device);
 /* rows per rank and 1024-row chunks per rank for a P-sharded run (pure host arithmetic). */
 size_t      icp_amd_rows_per_rank(size_t n_global, int world);
 size_t      icp_amd_chunks_per_rank(size_t n_global, int world);

@@ -257,6 +257,21 @@ def test_target_can_be_replaced_under_an_existing_source():
     assert np.array_equal(got, ref["idx"][-1])
 
 
+def test_init_is_optional_and_repeatable():
+    """icp_amd_init (context + code objects up front, for callers that overlap it with their I/O): fine before, between
+    and after other calls, from another thread too; a device that does not exist is an argument error."""
+    import threading
+    icp_amd.init()
+    t = threading.Thread(target=icp_amd.init, args=(0,))
+    t.start(); t.join()
+    g = golden("syn256")
+    a = icp_amd.icp_gpu_optimized(g["P"], g["Q"], 2)
+    icp_amd.init(0)
+    assert np.array_equal(icp_amd.icp_gpu_optimized(g["P"], g["Q"], 2), a)
+    with pytest.raises(icp_amd.IcpAmdError):
+        icp_amd.init(icp_amd.device_count())
+
+
 def test_cli_matches_reference_output(tmp_path):
     """GPUICP on the 30-point pair: same stdout line shape, same output file format as the reference
     (reference src/gpu/main.cu:79-80); usage and method errors abort like runtime_assert."""

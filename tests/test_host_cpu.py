@@ -31,7 +31,7 @@ def test_no_cpu_fallback():
         pytest.skip("a GPU is present")
     P = np.zeros((4, 3))
     for fn in (lambda: icp_amd.icp_gpu_optimized(P, P, 1), lambda: icp_amd.centroid(P),
-               lambda: icp_amd.correspondences(P, np.zeros(3), P), lambda: icp_amd.Engine()):
+               lambda: icp_amd.correspondences(P, np.zeros(3), P), lambda: icp_amd.Engine(), lambda: icp_amd.init()):
         with pytest.raises(icp_amd.IcpAmdError) as ei:
             fn()
         assert ei.value.code == -2 and "no CPU fallback" in str(ei.value)
