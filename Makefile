@@ -17,13 +17,16 @@ $(CSRC)/search_mfma.o: $(CSRC)/search_mfma.hip $(CSRC)/kernels.h $(CSRC)/exact.h
 $(CSRC)/grid.o: $(CSRC)/grid.hip $(CSRC)/kernels.h $(CSRC)/exact.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
+$(CSRC)/devmem.o: $(CSRC)/devmem.cpp $(CSRC)/kernels.h
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
 $(CSRC)/engine.o: $(CSRC)/engine.hip $(CSRC)/kernels.h include/icp_amd.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
 $(CSRC)/hostio.o: $(CSRC)/hostio.cpp include/icp_amd.h
 	$(CXX) -O2 -std=c++17 -fPIC -ffp-contract=off -Wall -Wextra -c $< -o $@
 
-$(LIB): $(CSRC)/kernels.o $(CSRC)/search_mfma.o $(CSRC)/grid.o $(CSRC)/engine.o $(CSRC)/hostio.o
+$(LIB): $(CSRC)/kernels.o $(CSRC)/search_mfma.o $(CSRC)/grid.o $(CSRC)/devmem.o $(CSRC)/engine.o $(CSRC)/hostio.o
 	$(HIPCC) --offload-arch=$(ARCH) -shared -o $@ $^ -ldl
 
 bin/GPUICP: $(CSRC)/gpuicp_main.cpp $(LIB) include/icp_amd.h

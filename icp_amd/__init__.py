@@ -37,6 +37,13 @@ def init(device=-1):
     check(lib().icp_amd_init(C.c_int(device)))
 
 
+def cache_trim():
+    """icp_amd_cache_trim: give the device memory the library keeps for reuse back to the driver; returns the bytes released."""
+    f = lib().icp_amd_cache_trim
+    f.restype = C.c_size_t
+    return int(f())
+
+
 def rows_per_rank(n_global, world):
     return int(lib().icp_amd_rows_per_rank(n_global, world))
 

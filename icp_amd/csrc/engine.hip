@@ -70,14 +70,21 @@ extern "C" int icp_amd_init(int device)
 {
     RCCHK(require_device(device < 0 ? env_int("ICP_AMD_DEVICE", 0) : device));
     double *buf = nullptr;
-    HIPCHK(hipMalloc(&buf, 8 * sizeof(double)));
+    HIPCHK(dmalloc(&buf, 8 * sizeof(double)));
     hipError_t er = hipMemsetAsync(buf, 0, 8 * sizeof(double), nullptr);
     if (er == hipSuccess) er = finalize_centroid(nullptr, buf, 1, 1.0, buf + 3);
     if (er == hipSuccess) er = grid_warmup(nullptr);
     if (er == hipSuccess) er = hipStreamSynchronize(nullptr);
-    (void)hipFree(buf);
+    (void)dfree(buf);
     HIPCHK(er);
     return ICP_AMD_OK;
+}
+
+extern "C" size_t icp_amd_cache_trim(void)
+{
+    const size_t held = dcache_held();
+    dcache_trim();
+    return held;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -170,7 +177,7 @@ struct icp_amd_engine {
     unsigned search_launches = 0;
 };
 
-static void free_dev(void *p) { if (p) (void)hipFree(p); }
+static void free_dev(void *p) { if (p) (void)dfree(p); }
 
 static int env_int(const char *name, int dflt)
 {
@@ -203,9 +210,9 @@ extern "C" int icp_amd_create(icp_amd_engine **out, const icp_amd_options *opt_i
         if (er != hipSuccess) { delete e; return fail(ICP_AMD_EHIP, "hipStreamCreate: %s", hipGetErrorString(er)); }
         e->own_stream = true;
     }
-    hipError_t er = hipMalloc(&e->qc, 3 * sizeof(double));
-    if (er == hipSuccess) er = hipMalloc(&e->pc, 3 * sizeof(double));
-    if (er == hipSuccess) er = hipMalloc(&e->rec, (kSolveW + 3) * sizeof(double));
+    hipError_t er = dmalloc(&e->qc, 3 * sizeof(double));
+    if (er == hipSuccess) er = dmalloc(&e->pc, 3 * sizeof(double));
+    if (er == hipSuccess) er = dmalloc(&e->rec, (kSolveW + 3) * sizeof(double));
     if (er != hipSuccess) { icp_amd_destroy(e); return fail(ICP_AMD_ENOMEM, "hipMalloc: %s", hipGetErrorString(er)); }
     *out = e;
     return ICP_AMD_OK;
@@ -235,7 +242,7 @@ static int ensure_stage(icp_amd_engine *e, size_t rows)
     free_dev(e->stage);
     e->stage = nullptr;
     e->stage_rows = 0;
-    HIPCHK(hipMalloc(&e->stage, rows * 3 * sizeof(double)));
+    HIPCHK(dmalloc(&e->stage, rows * 3 * sizeof(double)));
     e->stage_rows = rows;
     return ICP_AMD_OK;
 }
@@ -256,10 +263,10 @@ extern "C" int icp_amd_set_target(icp_amd_engine *e, const double *Q, size_t m)
         free_dev(e->q_store); free_dev(e->qrec); free_dev(e->q_rec);
         e->q_store = nullptr; e->qrec = nullptr; e->q_rec = nullptr;
         e->m_pad = 0;
-        HIPCHK(hipMalloc(&e->q_store, 3 * m_pad * sizeof(double)));
-        HIPCHK(hipMalloc(&e->q_rec, m_pad * sizeof(double4)));
-        HIPCHK(hipMalloc(&e->qrec, 16 * m_pad));
-        if (!e->qmax2_dev) HIPCHK(hipMalloc(&e->qmax2_dev, sizeof(unsigned long long)));
+        HIPCHK(dmalloc(&e->q_store, 3 * m_pad * sizeof(double)));
+        HIPCHK(dmalloc(&e->q_rec, m_pad * sizeof(double4)));
+        HIPCHK(dmalloc(&e->qrec, 16 * m_pad));
+        if (!e->qmax2_dev) HIPCHK(dmalloc(&e->qmax2_dev, sizeof(unsigned long long)));
         e->m_pad = m_pad;
         e->Qz = Soa3{e->q_store, e->q_store + m_pad, e->q_store + 2 * m_pad, e->q_rec};
     }
@@ -269,7 +276,7 @@ extern "C" int icp_amd_set_target(icp_amd_engine *e, const double *Q, size_t m)
     // Q_center = Q.mean(0); Q -= Q_center (reference src/cpu/icp.cpp:197-198), then SoA + inf padding
     const size_t chunks = (m + kChunk - 1) / kChunk;
     double *part = nullptr;
-    HIPCHK(hipMalloc(&part, chunks * kCenW * sizeof(double)));
+    HIPCHK(dmalloc(&part, chunks * kCenW * sizeof(double)));
     hipError_t er = colsum_partials(e->stream, e->stage, Soa3{nullptr, nullptr, nullptr}, m, part);
     if (er == hipSuccess) er = finalize_centroid(e->stream, part, chunks, (double)m, e->qc);
     if (er == hipSuccess)
@@ -279,7 +286,7 @@ extern "C" int icp_amd_set_target(icp_amd_engine *e, const double *Q, size_t m)
     unsigned long long bits = 0;
     if (er == hipSuccess) er = hipMemcpyAsync(&bits, e->qmax2_dev, sizeof bits, hipMemcpyDeviceToHost, e->stream);
     if (er == hipSuccess) er = hipStreamSynchronize(e->stream);
-    (void)hipFree(part);
+    (void)dfree(part);
     HIPCHK(er);
     double qmax2;
     memcpy(&qmax2, &bits, sizeof qmax2);
@@ -390,8 +397,8 @@ static int ensure_split_buffers(icp_amd_engine *e)
     if (need > e->split_cap) {
         free_dev(e->keys); free_dev(e->idxs);
         e->keys = nullptr; e->idxs = nullptr; e->split_cap = 0;
-        HIPCHK(hipMalloc(&e->keys, need * sizeof(double)));
-        HIPCHK(hipMalloc(&e->idxs, need * sizeof(uint32_t)));
+        HIPCHK(dmalloc(&e->keys, need * sizeof(double)));
+        HIPCHK(dmalloc(&e->idxs, need * sizeof(uint32_t)));
         e->split_cap = need;
     }
     return ICP_AMD_OK;
@@ -421,14 +428,14 @@ static int prepare_grid_source(icp_amd_engine *e)
     e->P.rec = nullptr;
     if (n && wants_grid(e)) {
         if (!e->gscratch.list) HIPCHK(grid_scratch_alloc(n_pad, &e->gscratch));
-        if (!e->grid_out) HIPCHK(hipMalloc(&e->grid_out, n_pad * sizeof(double2)));
+        if (!e->grid_out) HIPCHK(dmalloc(&e->grid_out, n_pad * sizeof(double2)));
         if (env_int("ICP_AMD_GRID_SRCREC", 1)) {
-            if (!e->p_rec) HIPCHK(hipMalloc(&e->p_rec, 2 * n_pad * sizeof(double4)));
+            if (!e->p_rec) HIPCHK(dmalloc(&e->p_rec, 2 * n_pad * sizeof(double4)));
             e->P.rec = e->p_rec;
             HIPCHK(build_source_rec(e->stream, e->P, n));
         }
         if (env_int("ICP_AMD_GRID_ORDER", 1)) {
-            if (!e->order) HIPCHK(hipMalloc(&e->order, n_pad * sizeof(uint32_t)));
+            if (!e->order) HIPCHK(dmalloc(&e->order, n_pad * sizeof(uint32_t)));
             HIPCHK(grid_order(e->stream, e->P, n, e->order));
             e->order_ok = true;
         }
@@ -457,8 +464,8 @@ extern "C" int icp_amd_set_source(icp_amd_engine *e, const double *P, size_t n)
         free_dev(e->p_rec); free_dev(e->grid_out);
         e->p_rec = nullptr; e->grid_out = nullptr;
         e->p_store = nullptr; e->idx = nullptr; e->order = nullptr; e->n_pad = 0;
-        HIPCHK(hipMalloc(&e->p_store, 3 * n_pad * sizeof(double)));
-        HIPCHK(hipMalloc(&e->idx, n_pad * sizeof(uint32_t)));
+        HIPCHK(dmalloc(&e->p_store, 3 * n_pad * sizeof(double)));
+        HIPCHK(dmalloc(&e->idx, n_pad * sizeof(uint32_t)));
         HIPCHK(hipMemset(e->idx, 0xFF, n_pad * sizeof(uint32_t)));
         e->n_pad = n_pad;
         e->P = Soa3{e->p_store, e->p_store + n_pad, e->p_store + 2 * n_pad};
@@ -476,8 +483,8 @@ extern "C" int icp_amd_set_source(icp_amd_engine *e, const double *P, size_t n)
     } else if (total != e->total_chunks || !e->own_part) {
         if (e->own_part) { free_dev(e->cov_part); free_dev(e->cen_part); }
         e->cov_part = e->cen_part = nullptr;
-        HIPCHK(hipMalloc(&e->cov_part, total * kCovW * sizeof(double)));
-        HIPCHK(hipMalloc(&e->cen_part, total * kCenW * sizeof(double)));
+        HIPCHK(dmalloc(&e->cov_part, total * kCovW * sizeof(double)));
+        HIPCHK(dmalloc(&e->cen_part, total * kCenW * sizeof(double)));
         e->own_part = true;
     }
     e->total_chunks = total;
@@ -849,8 +856,8 @@ struct MultiRun {
         for (icp_amd_engine *e : eng) icp_amd_destroy(e);
         for (size_t g = 0; g < dev.size(); ++g) {
             (void)hipSetDevice(dev[g]);
-            if (g < cov.size() && cov[g]) (void)hipFree(cov[g]);
-            if (g < cen.size() && cen[g]) (void)hipFree(cen[g]);
+            if (g < cov.size() && cov[g]) (void)dfree(cov[g]);
+            if (g < cen.size() && cen[g]) (void)dfree(cen[g]);
         }
         for (Rccl::comm_t c : comm)
             if (c) g_rccl.CommDestroy(c);
@@ -893,8 +900,8 @@ extern "C" int icp_amd_run_multi(const double *P, size_t n, const double *Q, siz
     r.comm.assign(G, nullptr);
     for (int g = 0; g < G; ++g) {
         RCCHK(require_device(r.dev[g]));
-        HIPCHK(hipMalloc(&r.cov[g], (size_t)G * cpr * kCovW * sizeof(double)));
-        HIPCHK(hipMalloc(&r.cen[g], (size_t)G * cpr * kCenW * sizeof(double)));
+        HIPCHK(dmalloc(&r.cov[g], (size_t)G * cpr * kCovW * sizeof(double)));
+        HIPCHK(dmalloc(&r.cen[g], (size_t)G * cpr * kCenW * sizeof(double)));
         HIPCHK(hipMemset(r.cov[g], 0, (size_t)G * cpr * kCovW * sizeof(double)));
         HIPCHK(hipMemset(r.cen[g], 0, (size_t)G * cpr * kCenW * sizeof(double)));
         icp_amd_options opt;
@@ -994,11 +1001,11 @@ extern "C" int icp_amd_batch_create(icp_amd_batch **out, int device, size_t batc
     if (!b) return fail(ICP_AMD_ENOMEM, "out of host memory");
     b->device = device; b->batch = batch; b->n = n; b->m = m;
     hipError_t er = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking);
-    if (er == hipSuccess) er = hipMalloc(&b->P_in, batch * n * 3 * sizeof(double));
-    if (er == hipSuccess) er = hipMalloc(&b->Q_in, batch * m * 3 * sizeof(double));
-    if (er == hipSuccess) er = hipMalloc(&b->P_out, batch * n * 3 * sizeof(double));
-    if (er == hipSuccess) er = hipMalloc(&b->rec, batch * kSolveW * sizeof(double));
-    if (er == hipSuccess) er = hipMalloc(&b->idx, batch * n * sizeof(uint32_t));
+    if (er == hipSuccess) er = dmalloc(&b->P_in, batch * n * 3 * sizeof(double));
+    if (er == hipSuccess) er = dmalloc(&b->Q_in, batch * m * 3 * sizeof(double));
+    if (er == hipSuccess) er = dmalloc(&b->P_out, batch * n * 3 * sizeof(double));
+    if (er == hipSuccess) er = dmalloc(&b->rec, batch * kSolveW * sizeof(double));
+    if (er == hipSuccess) er = dmalloc(&b->idx, batch * n * sizeof(uint32_t));
     if (er != hipSuccess) {
         icp_amd_batch_destroy(b);
         return fail(er == hipErrorOutOfMemory ? ICP_AMD_ENOMEM : ICP_AMD_EHIP, "icp_amd_batch_create: %s", hipGetErrorString(er));
@@ -1092,8 +1099,8 @@ extern "C" int icp_amd_run_batch(const double *P, const double *Q, size_t batch,
 namespace {
 struct DevBuf {
     void *p = nullptr;
-    ~DevBuf() { if (p) (void)hipFree(p); }
-    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 8); }
+    ~DevBuf() { if (p) (void)dfree(p); }
+    hipError_t alloc(size_t bytes) { return dmalloc(&p, bytes ? bytes : 8); }
     template <class T> T *as() { return (T *)p; }
 };
 

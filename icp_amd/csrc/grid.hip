@@ -478,9 +478,9 @@ hipError_t grid_warmup(hipStream_t s)
 void grid_free(Grid *g)
 {
     if (!g) return;
-    if (g->start) (void)hipFree(g->start);
-    if (g->perm) (void)hipFree(g->perm);
-    if (g->rec) (void)hipFree(g->rec);
+    if (g->start) (void)dfree(g->start);
+    if (g->perm) (void)dfree(g->perm);
+    if (g->rec) (void)dfree(g->rec);
     *g = Grid{};
 }
 
@@ -540,7 +540,7 @@ static hipError_t grid_sort(hipStream_t s, Soa3 Qz, size_t m, double per_cell, b
     uint32_t *cell = nullptr, *counts = nullptr, *cursor = nullptr, *block_sums = nullptr;
     unsigned long long host_bb[6];
 #define GRID_TRY(expr) do { e = (expr); if (e != hipSuccess) goto done; } while (0)
-    GRID_TRY(hipMalloc(&bb, 6 * sizeof(unsigned long long)));
+    GRID_TRY(dmalloc(&bb, 6 * sizeof(unsigned long long)));
     GRID_TRY(hipMemsetAsync(bb, 0xFF, 3 * sizeof(unsigned long long), s));
     GRID_TRY(hipMemsetAsync(bb + 3, 0x00, 3 * sizeof(unsigned long long), s));
     {
@@ -567,12 +567,12 @@ static hipError_t grid_sort(hipStream_t s, Soa3 Qz, size_t m, double per_cell, b
         // Scans are surfaces: most cells of the bounding volume stay empty and the occupied ones are fuller than
         // planned.  Count the occupied cells and shrink the cell edge until they hold about per_cell points on average
         // (assuming the occupied count grows like 1/h^2; volume-filling clouds pass at once), within the cell budget.
-        GRID_TRY(hipMalloc(&cell, m * sizeof(uint32_t)));
+        GRID_TRY(dmalloc(&cell, m * sizeof(uint32_t)));
         double h_scale = 1.0;
         for (int round = 0;; ++round) {
             choose_cells(lo, hi, m, per_cell, h_scale, &g->d);
             g->cells = (size_t)g->d.dim[0] * (size_t)g->d.dim[1] * (size_t)g->d.dim[2];
-            GRID_TRY(hipMalloc(&counts, g->cells * sizeof(uint32_t)));
+            GRID_TRY(dmalloc(&counts, g->cells * sizeof(uint32_t)));
             GRID_TRY(hipMemsetAsync(counts, 0, g->cells * sizeof(uint32_t), s));
             grid_count_kernel<<<(unsigned)((m + kWG - 1) / kWG), kWG, 0, s>>>(Qz.x, Qz.y, Qz.z, m, g->d, cell, counts);
             GRID_TRY(hipGetLastError());
@@ -587,19 +587,19 @@ static hipError_t grid_sort(hipStream_t s, Soa3 Qz, size_t m, double per_cell, b
             if (avg <= 2.0 * per_cell) break;
             double f = sqrt(per_cell / avg);
             h_scale *= f < 0.25 ? 0.25 : f;
-            (void)hipFree(counts);
+            (void)dfree(counts);
             counts = nullptr;
         }
     }
-    GRID_TRY(hipMalloc(&g->start, (g->cells + 1) * sizeof(uint32_t)));
-    GRID_TRY(hipMalloc(&g->perm, m * sizeof(uint32_t)));
-    if (with_coords) GRID_TRY(hipMalloc(&g->rec, m * sizeof(double4)));
-    GRID_TRY(hipMalloc(&cursor, g->cells * sizeof(uint32_t)));
+    GRID_TRY(dmalloc(&g->start, (g->cells + 1) * sizeof(uint32_t)));
+    GRID_TRY(dmalloc(&g->perm, m * sizeof(uint32_t)));
+    if (with_coords) GRID_TRY(dmalloc(&g->rec, m * sizeof(double4)));
+    GRID_TRY(dmalloc(&cursor, g->cells * sizeof(uint32_t)));
     if (g->cells <= 65536) {
         grid_scan_kernel<<<1, 1024, 0, s>>>(counts, g->cells, g->start, cursor);
     } else {
         const size_t blocks = (g->cells + kScanPerBlock - 1) / kScanPerBlock;   // <= 4096
-        GRID_TRY(hipMalloc(&block_sums, 3 * (blocks + 1) * sizeof(uint32_t)));
+        GRID_TRY(dmalloc(&block_sums, 3 * (blocks + 1) * sizeof(uint32_t)));
         uint32_t *block_off = block_sums + blocks + 1, *unused_copy = block_off + blocks + 1;
         grid_scan_sums_kernel<<<(unsigned)blocks, kWG, 0, s>>>(counts, g->cells, block_sums);
         GRID_TRY(hipGetLastError());
@@ -614,11 +614,11 @@ static hipError_t grid_sort(hipStream_t s, Soa3 Qz, size_t m, double per_cell, b
     g->ok = true;
 #undef GRID_TRY
 done:
-    if (bb) (void)hipFree(bb);
-    if (cell) (void)hipFree(cell);
-    if (counts) (void)hipFree(counts);
-    if (cursor) (void)hipFree(cursor);
-    if (block_sums) (void)hipFree(block_sums);
+    if (bb) (void)dfree(bb);
+    if (cell) (void)dfree(cell);
+    if (counts) (void)dfree(counts);
+    if (cursor) (void)dfree(cursor);
+    if (block_sums) (void)dfree(block_sums);
     if (e != hipSuccess) grid_free(g);
     return e;
 }
@@ -689,9 +689,9 @@ hipError_t grid_scratch_alloc(size_t n, GridScratch *sc)
     sc->row_cap = getenv("ICP_AMD_GRID_ROWCAP") ? atoi(getenv("ICP_AMD_GRID_ROWCAP")) : 64;
     sc->eval_cap = getenv("ICP_AMD_GRID_EVALCAP") ? atoi(getenv("ICP_AMD_GRID_EVALCAP")) : 768;
     sc->defer_always = getenv("ICP_AMD_GRID_DEFER") && !strcmp(getenv("ICP_AMD_GRID_DEFER"), "always");
-    hipError_t e = hipMalloc(&sc->count2, 2 * sizeof(uint32_t));
+    hipError_t e = dmalloc(&sc->count2, 2 * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMemset(sc->count2, 0, 2 * sizeof(uint32_t));
-    if (e == hipSuccess) e = hipMalloc(&sc->list, (n ? n : 1) * sizeof(uint32_t));
+    if (e == hipSuccess) e = dmalloc(&sc->list, (n ? n : 1) * sizeof(uint32_t));
     if (e == hipSuccess) e = hipHostMalloc((void **)&sc->host_mem, sizeof(uint32_t), hipHostMallocMapped);
     if (e == hipSuccess) {
         *sc->host_mem = 0;
@@ -704,8 +704,8 @@ hipError_t grid_scratch_alloc(size_t n, GridScratch *sc)
 void grid_scratch_free(GridScratch *sc)
 {
     if (!sc) return;
-    if (sc->count2) (void)hipFree(sc->count2);
-    if (sc->list) (void)hipFree(sc->list);
+    if (sc->count2) (void)dfree(sc->count2);
+    if (sc->list) (void)dfree(sc->list);
     if (sc->host_mem) (void)hipHostFree((void *)sc->host_mem);
     *sc = GridScratch{};
 }

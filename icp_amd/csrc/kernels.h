@@ -17,6 +17,14 @@ enum SearchVariant { kExact = 1, kFma = 2, kF32 = 3, kGrid = 4, kExpanded = 5 /*
 constexpr size_t kPadRows = 2048;  // clouds are padded to this many rows (covers every kernel's tile)
 constexpr size_t kSplitGran = 64;  // target splits are whole multiples of this many targets (>= every cb, even)
 
+// Device memory through a small cache (devmem.cpp): same contracts as hipMalloc / hipFree, but released blocks are kept
+// (ICP_AMD_CACHE_MB, default 2048) and reused by later requests of about the same size.
+hipError_t dmalloc_bytes(void **p, size_t bytes);
+template <class T> inline hipError_t dmalloc(T **p, size_t bytes) { return dmalloc_bytes((void **)p, bytes); }
+hipError_t dfree(void *p);
+void dcache_trim();      // give every kept block back to the driver
+size_t dcache_held();    // bytes kept
+
 struct Soa3 {            // device SoA view of a cloud
     double *x, *y, *z;
     // optional row-major copy for random access by index, rec[j] = {x, y, z, unused}: one 32-byte record (one cache

@@ -91,6 +91,11 @@ void        icp_amd_default_options(icp_amd_options *opt);
  * caller with input files to parse can run it on another thread meanwhile, as GPUICP does; every other entry point
  * initialises on demand. */
 int         icp_amd_init(int device);
+/* Device memory released by the library (icp_amd_destroy, a cloud of another size, the one-shot calls) is kept for the
+ * next request of about the same size instead of going back to the driver: hipFree costs 0.1 ms per block, a third of a
+ * small one-shot registration.  ICP_AMD_CACHE_MB bounds what is kept (default 2048, 0 = keep nothing);
+ * icp_amd_cache_trim returns it all to the driver now and reports how many bytes that was.  No reference counterpart. */
+size_t      icp_amd_cache_trim(void);
 /* rows per rank and 1024-row chunks per rank for a P-sharded run (pure host arithmetic). */
 size_t      icp_amd_rows_per_rank(size_t n_global, int world);
 size_t      icp_amd_chunks_per_rank(size_t n_global, int world);

@@ -272,6 +272,26 @@ def test_init_is_optional_and_repeatable():
         icp_amd.init(icp_amd.device_count())
 
 
+def test_released_device_memory_is_reused_and_can_be_trimmed():
+    """devmem.cpp: blocks released by a finished registration are kept and handed to the next one (dirty, so this is also a
+    test that nothing relies on fresh zeroed memory); icp_amd_cache_trim gives them back.  Results do not change."""
+    g = golden("syn3k_4k")
+    icp_amd.cache_trim()
+    a, ta = icp_amd.icp_gpu_optimized(g["P"], g["Q"], 3, trace=True)
+    held = icp_amd.cache_trim()
+    assert held > 3 * 8 * (len(g["P"]) + len(g["Q"]))          # at least the two clouds' worth of blocks was being kept
+    assert icp_amd.cache_trim() == 0
+    for _ in range(3):                                           # second and third run on recycled blocks
+        b, tb = icp_amd.icp_gpu_optimized(g["P"], g["Q"], 3, trace=True)
+        assert np.array_equal(a, b) and np.array_equal(ta["idx"], tb["idx"]) and np.array_equal(ta["cov"], tb["cov"])
+    # a different size in between, then the first size again
+    h = golden("cow_tr1")
+    icp_amd.icp_gpu_optimized(h["P"], h["Q"], 2)
+    b = icp_amd.icp_gpu_optimized(g["P"], g["Q"], 3)
+    assert np.array_equal(a, b)
+    assert icp_amd.cache_trim() > 0
+
+
 def test_cli_matches_reference_output(tmp_path):
     """GPUICP on the 30-point pair: same stdout line shape, same output file format as the reference
     (reference src/gpu/main.cu:79-80); usage and method errors abort like runtime_assert."""
