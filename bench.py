@@ -307,7 +307,7 @@ def main():
         if geo["variant"] == "f32":
             out["roofline"]["traffic"] = measured_traffic("search_f32_kernel", N, M, world)
             out["roofline"]["traffic_note"] = ("bytes per launch at the L2's memory side (FETCH_SIZE x 2 + WRITE_SIZE, separate "
-                                               "rocprofv3 --pmc passes, profiles/r1_v7_pmc_*.txt); includes Infinity-Cache hits; "
+                                               "rocprofv3 --pmc passes, profiles/r1_v8_pmc_*.txt); includes Infinity-Cache hits; "
                                                "the kernel is VALU bound: this is 0.14 TB/s")
         if grid:
             out["grid_search"] = grid
