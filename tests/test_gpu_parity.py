@@ -292,6 +292,33 @@ def test_released_device_memory_is_reused_and_can_be_trimmed():
     assert icp_amd.cache_trim() > 0
 
 
+def test_concurrent_registrations_from_several_threads():
+    """The library keeps no hidden global state between engines: registrations running at the same time on four host
+    threads (ctypes releases the GIL; each call has its own engine and stream, they share the device-memory cache and the
+    thread-local error text) return what they return one after the other."""
+    import threading
+    cases = [golden(n) for n in ("cow_tr1", "syn3k_4k", "syn1k", "lattice")]
+    want = [icp_amd.icp_gpu_optimized(g["P"], g["Q"], 4) for g in cases]
+    got, errs = {}, []
+    def work(k, rounds):
+        try:
+            for r in range(rounds):
+                g = cases[(k + r) % len(cases)]
+                got[(k, r)] = ((k + r) % len(cases), icp_amd.icp_gpu_optimized(g["P"], g["Q"], 4))
+            with pytest.raises(icp_amd.IcpAmdError) as ei:      # an error in one thread does not leak into another's text
+                icp_amd.icp_gpu_optimized(np.zeros((0, 3)), cases[0]["Q"], 1)
+            assert "empty" in str(ei.value) or "NULL" in str(ei.value) or str(ei.value)
+        except Exception as exc:   # noqa: BLE001 -- reported below, in the main thread
+            errs.append(repr(exc))
+    threads = [threading.Thread(target=work, args=(k, 6)) for k in range(4)]
+    for t in threads: t.start()
+    for t in threads: t.join()
+    assert not errs, errs
+    assert len(got) == 24
+    for (k, r), (c, out) in got.items():
+        assert np.array_equal(out, want[c]), (k, r, c)
+
+
 def test_cli_matches_reference_output(tmp_path):
     """GPUICP on the 30-point pair: same stdout line shape, same output file format as the reference
     (reference src/gpu/main.cu:79-80); usage and method errors abort like runtime_assert."""
