@@ -296,8 +296,9 @@ def main():
             "iters_per_sec": args.steps / dt,
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[3]: synthetic %d x %d points, source rows sharded over %d GPU(s), "
-                                   "target replicated" % (N, M, world),
+            "config": {"workload": "%s: synthetic %d x %d points, source rows sharded over %d GPU(s), target replicated"
+                                   % ("BASELINE configs[3]" if N == M == 1000000 else "BASELINE configs[2]" if N == M == 100000
+                                      else "configs[3]-shaped workload at another size", N, M, world),
                        "n": N, "m": M, "parallelism": "p-shard%d" % world, "search": geo,
                        "search_mode": "brute force: all N x M distances evaluated every iteration"},
             # dominant kernel (the correspondence search, > 99 % of the step), from its own hipEvent-timed launches
