@@ -249,7 +249,7 @@ def main():
             td.barrier()
         torch.cuda.synchronize()
 
-    def run(search, steps, warmup):
+    def run(search, steps, warmup, repeats=0):
         """`steps` timed iterations after `warmup` untimed ones: (seconds [max over ranks], search-kernel avg ms,
         launches, geometry, last iteration's outputs, local rows)."""
         runner = icpdist.ShardedIcp(P, Q, rank=rank, world=world, device=local_rank, search=search, kernel_timing=True)
@@ -270,12 +270,21 @@ def main():
         avg_ms, _, launches = runner.engine.kernel_ms()
         res = (dt, avg_ms, launches, runner.engine.search_geometry(), runner.engine.get_last(), runner.n_local,
                runner.engine.grid_stats())
+        # outside the timed region: a few more steps, each bracketed on its own, for the spread (median + min)
+        for _ in range(repeats):
+            barrier()
+            t1 = time.perf_counter()
+            runner.step()
+            barrier()
+            step_samples.append((time.perf_counter() - t1) * 1e3)
         runner.close()
         return res
 
+    step_samples = []
+
     # Headline: the brute-force search (every one of the N x M distances is evaluated each iteration) -- the path the
     # metric "distance evals/s" and the VALU roofline are defined on.
-    dt, search_avg_ms, launches, geo, last, n_local, _ = run(args.search, args.steps, args.warmup)
+    dt, search_avg_ms, launches, geo, last, n_local, _ = run(args.search, args.steps, args.warmup, repeats=5)
     grid = None
     if not args.no_grid and args.search != "grid":
         # The same iterations with the grid search (identical results, a fraction of the distance evaluations):
@@ -304,6 +313,10 @@ def main():
             # dominant kernel (the correspondence search, > 99 % of the step), from its own hipEvent-timed launches
             "roofline": roofline(geo["variant"], n_local, M, search_avg_ms, launches),
             "rms_last": last["rms"],
+            "step_ms_samples": {"values": [round(v, 4) for v in step_samples], "median": float(np.median(step_samples)),
+                                "min": float(min(step_samples)),
+                                "note": "five more iterations after the timed region, each bracketed by its own barrier + "
+                                        "synchronize (rank 0's clock); not part of `value`"},
         }
         if geo["variant"] == "f32":
             out["roofline"]["traffic"] = measured_traffic("search_f32_kernel", N, M, world)
