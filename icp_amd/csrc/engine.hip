@@ -851,6 +851,8 @@ struct MultiRun {
     std::vector<double *> cov, cen;
     std::vector<int> dev;
     std::vector<Rccl::comm_t> comm;
+    bool by_copies = false;                 // exchange with peer copies instead of RCCL (a device listed twice; ICP_AMD_MULTI_EXCHANGE=copy)
+    std::vector<hipEvent_t> ready, done;    // by_copies: per engine, "my slot is written" / "I have read everybody's slot"
     ~MultiRun()
     {
         for (icp_amd_engine *e : eng) icp_amd_destroy(e);
@@ -858,15 +860,47 @@ struct MultiRun {
             (void)hipSetDevice(dev[g]);
             if (g < cov.size() && cov[g]) (void)dfree(cov[g]);
             if (g < cen.size() && cen[g]) (void)dfree(cen[g]);
+            if (g < ready.size() && ready[g]) (void)hipEventDestroy(ready[g]);
+            if (g < done.size() && done[g]) (void)hipEventDestroy(done[g]);
         }
         for (Rccl::comm_t c : comm)
             if (c) g_rccl.CommDestroy(c);
     }
 };
 
+// The same exchange without RCCL: every engine copies the other engines' slots into its own buffer (peer copies on its
+// own stream, ordered by events).  G (G - 1) small copies per exchange instead of one collective -- the way out when RCCL
+// cannot form the communicator (one device listed more than once: several shards per GPU) or is not installed.
+int all_gather_by_copies(MultiRun &r, std::vector<double *> &buf, size_t per)
+{
+    const int G = (int)r.eng.size();
+    for (int g = 0; g < G; ++g) {
+        HIPCHK(hipSetDevice(r.dev[g]));
+        HIPCHK(hipEventRecord(r.ready[g], r.eng[g]->stream));
+    }
+    for (int g = 0; g < G; ++g) {
+        HIPCHK(hipSetDevice(r.dev[g]));
+        for (int h = 0; h < G; ++h) {
+            if (h == g) continue;
+            HIPCHK(hipStreamWaitEvent(r.eng[g]->stream, r.ready[h], 0));
+            HIPCHK(hipMemcpyPeerAsync(buf[g] + (size_t)h * per, r.dev[g], buf[h] + (size_t)h * per, r.dev[h], per * sizeof(double),
+                                      r.eng[g]->stream));
+        }
+        HIPCHK(hipEventRecord(r.done[g], r.eng[g]->stream));
+    }
+    // nobody overwrites its slot (the next iteration's partials) before every reader has copied it
+    for (int h = 0; h < G; ++h) {
+        HIPCHK(hipSetDevice(r.dev[h]));
+        for (int g = 0; g < G; ++g)
+            if (g != h) HIPCHK(hipStreamWaitEvent(r.eng[h]->stream, r.done[g], 0));
+    }
+    return ICP_AMD_OK;
+}
+
 // in-place all-gather of the rank-major partial array of every device (slot g of device g's buffer is its contribution)
 int all_gather_partials(MultiRun &r, std::vector<double *> &buf, size_t per)
 {
+    if (r.by_copies) return all_gather_by_copies(r, buf, per);
     const int G = (int)r.eng.size();
     int rc = g_rccl.GroupStart();
     for (int g = 0; g < G && rc == 0; ++g)
@@ -885,15 +919,23 @@ extern "C" int icp_amd_run_multi(const double *P, size_t n, const double *Q, siz
     if (n == 0 || m == 0) return fail(ICP_AMD_EINVAL, "icp_amd_run_multi: empty cloud (n=%zu, m=%zu)", n, m);
     const int avail = icp_amd_device_count();
     if (avail <= 0) return fail(ICP_AMD_ENODEV, "no HIP device available; libicp_amd has no CPU fallback");
-    if (n_gpus < 1 || n_gpus > avail) return fail(ICP_AMD_EINVAL, "icp_amd_run_multi: n_gpus=%d but %d device(s) are visible", n_gpus, avail);
+    // an explicit device list may name a device more than once (several shards per GPU); without a list: one shard per GPU
+    if (n_gpus < 1 || n_gpus > 1024 || (!devices && n_gpus > avail))
+        return fail(ICP_AMD_EINVAL, "icp_amd_run_multi: n_gpus=%d but %d device(s) are visible", n_gpus, avail);
     const int G = n_gpus;
     if (G == 1 && !devices) return icp_amd_run(P, n, Q, m, iters, ICP_AMD_METHOD_SHARED_LOOP, P_out, tr);
-    if (!g_rccl.load()) {
-        const char *why = dlerror();   // one call: the message is cleared by reading it
-        return fail(ICP_AMD_EHIP, "icp_amd_run_multi: cannot load librccl.so (%s)", why ? why : "missing symbols");
-    }
     MultiRun r;
     for (int g = 0; g < G; ++g) r.dev.push_back(devices ? devices[g] : g);
+    for (int g = 0; g < G; ++g) {
+        if (r.dev[g] < 0 || r.dev[g] >= avail) return fail(ICP_AMD_EINVAL, "icp_amd_run_multi: device %d out of range [0,%d)", r.dev[g], avail);
+        for (int h = 0; h < g; ++h) r.by_copies |= r.dev[h] == r.dev[g];
+    }
+    if (const char *x = getenv("ICP_AMD_MULTI_EXCHANGE")) r.by_copies |= !strcmp(x, "copy");
+    if (!r.by_copies && !g_rccl.load()) {
+        const char *why = dlerror();   // one call: the message is cleared by reading it
+        return fail(ICP_AMD_EHIP, "icp_amd_run_multi: cannot load librccl.so (%s); ICP_AMD_MULTI_EXCHANGE=copy exchanges with peer copies instead",
+                    why ? why : "missing symbols");
+    }
     const size_t cpr = icp_amd_chunks_per_rank(n, G), rpr = cpr * kChunk;
     r.cov.assign(G, nullptr);
     r.cen.assign(G, nullptr);
@@ -916,7 +958,21 @@ extern "C" int icp_amd_run_multi(const double *P, size_t n, const double *Q, siz
         RCCHK(icp_amd_create(&e, &opt));
         r.eng.push_back(e);
     }
-    {
+    if (r.by_copies) {
+        r.ready.assign(G, nullptr);
+        r.done.assign(G, nullptr);
+        for (int g = 0; g < G; ++g) {
+            HIPCHK(hipSetDevice(r.dev[g]));
+            HIPCHK(hipEventCreateWithFlags(&r.ready[g], hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&r.done[g], hipEventDisableTiming));
+            for (int h = 0; h < G; ++h) {   // peer access where the copies cross devices (already enabled is fine)
+                if (r.dev[h] == r.dev[g]) continue;
+                int can = 0;
+                HIPCHK(hipDeviceCanAccessPeer(&can, r.dev[g], r.dev[h]));
+                if (can && hipDeviceEnablePeerAccess(r.dev[h], 0) == hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
+            }
+        }
+    } else {
         const int rc = g_rccl.CommInitAll(r.comm.data(), G, r.dev.data());
         if (rc != 0) return fail(ICP_AMD_EHIP, "ncclCommInitAll failed: %s", g_rccl.GetErrorString(rc));
     }

@@ -109,7 +109,10 @@ int icp_amd_run(const double *P_xyz, size_t n, const double *Q_xyz, size_t m, un
  *      single-device).  The source rows are sharded over the `n_gpus` devices (devices == NULL: ordinals 0..n_gpus-1),
  *      the target is replicated; per iteration the per-chunk partial sums are combined with two RCCL all-gathers over
  *      xGMI (librccl.so is loaded at run time, only by this call), every device then sums all chunks in index order and
- *      solves R, t redundantly.  Results are bit-identical to icp_amd_run for every n_gpus.  trace->idx: n per iteration. */
+ *      solves R, t redundantly.  Results are bit-identical to icp_amd_run for every n_gpus.  trace->idx: n per iteration.
+ *      An explicit `devices` list may name a device more than once (several shards per GPU); RCCL cannot form a communicator
+ *      over such a list, so the partial sums are then exchanged with peer copies ordered by events -- as they are, on any
+ *      list, when ICP_AMD_MULTI_EXCHANGE=copy is set (e.g. where librccl.so is not installed). */
 int icp_amd_run_multi(const double *P_xyz, size_t n, const double *Q_xyz, size_t m, unsigned iters,
                       int n_gpus, const int *devices, double *P_out, icp_amd_trace *trace);
 

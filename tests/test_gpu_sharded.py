@@ -146,3 +146,25 @@ def test_native_rccl_multi_entry_point():
     assert np.array_equal(icp_amd.icp_gpu_multi(P, Q, 3, 1), want)
     with pytest.raises(icp_amd.IcpAmdError):
         icp_amd.icp_gpu_multi(P, Q, 1, icp_amd.device_count() + 1)
+
+
+def test_native_multi_entry_point_several_shards_per_gpu(monkeypatch):
+    """icp_amd_run_multi with a device list that repeats device 0: the whole sharded control flow of the native entry point
+    on this one-GPU box -- shard arithmetic, one set-up thread per shard, engines sharing a device, the exchange (peer
+    copies ordered by events, because RCCL refuses a device listed twice), per-shard trace indices, empty trailing
+    shards.  Bit-identical to the single-engine run for every shard count."""
+    for n, m, iters in ((6000, 5000, 4), (700, 900, 3), (20000, 20000, 3)):
+        P, Q = synth.make_pair(n, m, seed=43)
+        want, trw = icp_amd.icp_gpu_optimized(P, Q, iters, trace=True)
+        for shards in (2, 3, 5):
+            got, trg = icp_amd.icp_gpu_multi(P, Q, iters, shards, devices=[0] * shards, trace=True)
+            assert np.array_equal(got, want), (n, shards)
+            for k in ("idx", "cov", "R", "t", "Pc"):
+                assert np.array_equal(trg[k], trw[k]), (n, shards, k)
+    # the same exchange on a list RCCL could serve
+    monkeypatch.setenv("ICP_AMD_MULTI_EXCHANGE", "copy")
+    P, Q = synth.make_pair(6000, 5000, seed=44)
+    assert np.array_equal(icp_amd.icp_gpu_multi(P, Q, 3, 1, devices=[0]), icp_amd.icp_gpu_optimized(P, Q, 3))
+    monkeypatch.delenv("ICP_AMD_MULTI_EXCHANGE")
+    with pytest.raises(icp_amd.IcpAmdError):
+        icp_amd.icp_gpu_multi(P, Q, 1, 2, devices=[0, icp_amd.device_count()])
