@@ -35,7 +35,7 @@ static int io_fail(int code, const std::string &msg) { return icp_amd_fail_(code
 // with empty fields skipped (strtok semantics); a field counts as a number as soon as strtod consumes a
 // prefix of it; a non-numeric field after the first line -- including the field of a trailing blank line --
 // is the error "Not a valid double !".  Two quirks of readCSV are kept as well, because they decide what a caller gets
-// from a well-formed file (tools/fuzz_csv.py compares against the reference's own reader, file by file):
+// from a well-formed file (tests/fuzz/fuzz_csv.py compares against the reference's own reader, file by file):
 //  * a file WITHOUT a header line and with two or more lines loses its last row: the reference stores the second line as
 //    the "header" text once the first line turned out to be numeric (csv.cpp:113-114,128-129) and then counts one line
 //    less (csv.cpp:147-148).  nblines, the values and the header text returned here are the reference's;

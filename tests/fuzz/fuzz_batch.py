@@ -2,7 +2,7 @@
 """Differential fuzzing of the multi-registration kernel: default (expanded form) vs EXACT variant vs the engine run
 alone on the same pair, on adversarial small clouds.  Exit code 1 on a mismatch."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np
 import icp_amd

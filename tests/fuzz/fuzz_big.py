@@ -2,7 +2,7 @@
 """Variant-against-variant fuzz at sizes the CPU oracle cannot follow (up to 300k points): grid vs F32 vs EXACT engines,
 several seeded iterations, on volume-filling, surface-like, clustered and partially overlapping clouds."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np
 import icp_amd

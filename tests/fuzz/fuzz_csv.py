@@ -3,9 +3,9 @@
 readCSV, compiled unmodified into oracle/_ref/ref_trace (build container only: CPU, no GPU).  Random small files made of
 numeric and non-numeric tokens, blanks, headers, ragged rows and both line endings; both readers must agree on
 success / failure and, on success, on shape and every bit of every value.
-    python tools/fuzz_csv.py [cases] [seed]"""
+    python tests/fuzz/fuzz_csv.py [cases] [seed]"""
 import os, struct, subprocess, sys, tempfile
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np
 import icp_amd

@@ -2,7 +2,7 @@
 """Fuzz of the optional hooks: random rejection distances against the loop composed from the oracle's stages, and
 iterate_until against fixed-count iteration."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np

@@ -4,9 +4,9 @@
 on as many random adversarial ones as time allows: lattices with exact ties, duplicates, tight clusters, near-ties a few
 ulp apart, wild scales and offsets, coplanar / collinear clouds, N != M.  Stage by stage from the reference's own
 P_k: centroid, correspondence indices and covariance bit-exact; S, R, t to 1e-12 where the covariance is well conditioned.
-    python tools/fuzz_oracle.py [seconds] [seed]"""
+    python tests/fuzz/fuzz_oracle.py [seconds] [seed]"""
 import os, subprocess, sys, tempfile, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 sys.path.insert(0, os.path.join(ROOT, "tests"))

@@ -3,7 +3,7 @@
 tests/test_gpu_sharded.py): random sizes and world sizes, including ranks that own no rows; results must be
 bit-identical to the single-engine run, on the AUTO (grid) and the brute-force search."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np

@@ -2,7 +2,7 @@
 """Differential fuzzing of the search variants (exact / fma / f32 / grid, several split counts) and the oracle on small
 adversarial clouds: lattices, duplicates, clusters, near-ties a few ulp apart, wild scales.  Exit code 1 on a mismatch."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np
 import icp_amd

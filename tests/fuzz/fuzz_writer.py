@@ -4,9 +4,9 @@ the reference executable itself (oracle/_ref/CPUICP = the reference's src/cpu/ma
 container only.  CPUICP registers a random pair and writes `point_cloud_result` + its "Squared actual mean diff" line;
 ref_trace gives the very doubles it wrote (same code, same inputs); the library's writer must reproduce the file byte
 for byte from those doubles, and its report the printed value, across scales 1e-8 .. 1e8 (both ostream notations).
-    python tools/fuzz_writer.py [cases] [seed]"""
+    python tests/fuzz/fuzz_writer.py [cases] [seed]"""
 import os, subprocess, sys, tempfile
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 import numpy as np

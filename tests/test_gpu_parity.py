@@ -389,7 +389,7 @@ def test_cli_against_the_reference_executable_on_random_pairs(tmp_path):
 
 
 def test_stage_level_f32_fallback_uses_the_requested_splits():
-    """Regression (found by tools/fuzz_variants.py): a target whose range defeats the fp32 bound makes the stage-level
+    """Regression (found by tests/fuzz/fuzz_variants.py): a target whose range defeats the fp32 bound makes the stage-level
     F32 search fall back to FMA; it must run with the same number of target splits the merge then reads."""
     rng = np.random.RandomState(4)
     for n, m, scale in ((2799, 142, 1e22), (1768, 796, 1e-25), (128, 3196, 1e17)):
@@ -401,10 +401,10 @@ def test_stage_level_f32_fallback_uses_the_requested_splits():
 
 
 def test_differential_fuzz_of_all_variants_short():
-    """A few seconds of tools/fuzz_variants.py: lattices, duplicates, clusters, few-ulp near-ties, wild scales, flat clouds;
+    """A few seconds of tests/fuzz/fuzz_variants.py: lattices, duplicates, clusters, few-ulp near-ties, wild scales, flat clouds;
     every search variant, stage level and seeded engine iterations, against the oracle."""
     import sys
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_variants.py"), "8", "11"], capture_output=True, text=True,
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fuzz", "fuzz_variants.py"), "8", "11"], capture_output=True, text=True,
                        timeout=200)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "mismatches 0" in r.stdout

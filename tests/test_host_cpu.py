@@ -79,10 +79,10 @@ def test_read_csv_matches_reference_behaviour(tmp_path):
 
 @pytest.mark.skipif(not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "ref_trace")), reason="needs oracle/_ref (build container)")
 def test_csv_readers_against_the_reference_reader_differential():
-    """tools/fuzz_csv.py, short: random small files through the reference's own readCSV (compiled unmodified into
+    """tests/fuzz/fuzz_csv.py, short: random small files through the reference's own readCSV (compiled unmodified into
     oracle/_ref/ref_trace) and through the three CSV entry points.  Same outcome, shape and bits on every file the
     library promises to read like the reference; an error (never data) on the files it documents as rejected."""
-    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    sys.path.insert(0, os.path.join(ROOT, "tests", "fuzz"))
     import fuzz_csv
     assert fuzz_csv.run(150, seed=11, verbose=False) == []
 
@@ -173,9 +173,9 @@ def test_write_cloud_and_report_format(tmp_path):
 
 @pytest.mark.skipif(not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "CPUICP")), reason="needs oracle/_ref (build container)")
 def test_writer_and_report_against_the_reference_executable():
-    """tools/fuzz_writer.py, short: `point_cloud_result` and the "Squared actual mean diff" line of the reference's own
+    """tests/fuzz/fuzz_writer.py, short: `point_cloud_result` and the "Squared actual mean diff" line of the reference's own
     CPUICP (unmodified main.cpp) are reproduced byte for byte from the doubles it held, across scales 1e-8 .. 1e8."""
-    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    sys.path.insert(0, os.path.join(ROOT, "tests", "fuzz"))
     import fuzz_writer
     compared, bad = fuzz_writer.run(40, seed=5, verbose=False)
     assert compared >= 30 and bad == []

@@ -106,10 +106,10 @@ def test_svd3_degenerate_and_random():
 
 @pytest.mark.skipif(not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "ref_trace")), reason="needs oracle/_ref (build container)")
 def test_oracle_against_the_reference_on_random_adversarial_clouds():
-    """tools/fuzz_oracle.py, short: the oracle against the unmodified reference (oracle/_ref/ref_trace) beyond the committed
+    """tests/fuzz/fuzz_oracle.py, short: the oracle against the unmodified reference (oracle/_ref/ref_trace) beyond the committed
     golden vectors -- lattices with exact ties, duplicates, clusters, few-ulp near-ties, wild scales, coplanar / collinear
     clouds, N != M.  Centroid, indices, covariance and the applied transform bit-exact, stage by stage."""
-    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    sys.path.insert(0, os.path.join(ROOT, "tests", "fuzz"))
     import fuzz_oracle
     cases, bad = fuzz_oracle.run(120.0, seed=3, verbose=False, max_cases=150)
     assert cases == 150 and bad == []
