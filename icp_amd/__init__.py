@@ -243,6 +243,19 @@ def icp_gpu_batch(P, Q, iterations):
         b.close()
 
 
+def run_batch(P, Q, iterations):
+    """icp_amd_run_batch: like icp_gpu_batch, any cloud size (large clouds go through ordinary engines, several at a time)."""
+    P = np.ascontiguousarray(P, dtype=np.float64)
+    Q = np.ascontiguousarray(Q, dtype=np.float64)
+    if P.ndim != 3 or Q.ndim != 3 or P.shape[0] != Q.shape[0] or P.shape[2] != 3 or Q.shape[2] != 3:
+        raise IcpAmdError(_lib.EINVAL, "expected P [batch, n, 3] and Q [batch, m, 3]")
+    b, n, m = P.shape[0], P.shape[1], Q.shape[1]
+    d = dict(P_out=np.empty_like(P), R=np.zeros((b, 3, 3)), t=np.zeros((b, 3)), idx=np.zeros((b, n), dtype=np.int32), rms=np.zeros(b))
+    check(lib().icp_amd_run_batch(_p(P), _p(Q), C.c_size_t(b), C.c_size_t(n), C.c_size_t(m), C.c_uint(iterations), _p(d["P_out"]),
+                                  _p(d["R"]), _p(d["t"]), _p(d["idx"]), _p(d["rms"])))
+    return d
+
+
 # ---- stage level (parity tests) --------------------------------------------------------------------
 def correspondences(P, Pc, Qz, search="exact", q_splits=1):
     P, Qz = _f64(P), _f64(Qz)

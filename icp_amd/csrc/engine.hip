@@ -13,6 +13,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <limits>
 #include <new>
 #include <string>
@@ -1140,6 +1141,42 @@ extern "C" int icp_amd_run_batch(const double *P, const double *Q, size_t batch,
                                  double *R, double *t, int32_t *idx, double *rms)
 {
     if (!P || !Q || !P_out) return fail(ICP_AMD_EINVAL, "icp_amd_run_batch: NULL argument");
+    if (batch == 0 || n == 0 || m == 0) return fail(ICP_AMD_EINVAL, "icp_amd_run_batch: empty batch or cloud (batch=%zu n=%zu m=%zu)", batch, n, m);
+    if (n > kBatchMaxN || m > kBatchMaxM) {
+        // Clouds too large for the one-workgroup-per-registration kernel: the registrations go through ordinary engines
+        // instead, a few at a time (one host thread, engine and stream each; the device-memory cache makes their set-up
+        // cheap), so that small launches of different registrations overlap on the device.  Same results as icp_amd_run.
+        RCCHK(require_device(env_int("ICP_AMD_DEVICE", 0)));
+        const size_t workers = std::min<size_t>(batch, (size_t)std::max(1, std::min(env_int("ICP_AMD_BATCH_WORKERS", 4), 64)));
+        std::vector<int> rcs(workers, ICP_AMD_OK);
+        std::vector<std::string> errs(workers);
+        auto work = [&](size_t w) {
+            icp_amd_options opt;
+            icp_amd_default_options(&opt);
+            opt.device = env_int("ICP_AMD_DEVICE", 0);
+            icp_amd_engine *e = nullptr;
+            int rc = icp_amd_create(&e, &opt);
+            for (size_t k = w; k < batch && rc == ICP_AMD_OK; k += workers) {
+                rc = icp_amd_set_target(e, Q + k * m * 3, m);
+                if (rc == ICP_AMD_OK) rc = icp_amd_set_source(e, P + k * n * 3, n);
+                if (rc == ICP_AMD_OK) rc = icp_amd_iterate(e, iters);
+                if (rc == ICP_AMD_OK) rc = icp_amd_get_source(e, P_out + k * n * 3);
+                if (rc == ICP_AMD_OK && iters && (R || t || idx || rms))
+                    rc = icp_amd_get_last(e, nullptr, idx ? idx + k * n : nullptr, nullptr, nullptr, R ? R + 9 * k : nullptr,
+                                          t ? t + 3 * k : nullptr, rms ? rms + k : nullptr);
+            }
+            if (rc != ICP_AMD_OK) errs[w] = icp_amd_last_error();
+            rcs[w] = rc;
+            icp_amd_destroy(e);
+        };
+        std::vector<std::thread> pool;
+        for (size_t w = 1; w < workers; ++w) pool.emplace_back(work, w);
+        work(0);
+        for (std::thread &th : pool) th.join();
+        for (size_t w = 0; w < workers; ++w)
+            if (rcs[w] != ICP_AMD_OK) return fail(rcs[w], "%s", errs[w].c_str());
+        return ICP_AMD_OK;
+    }
     icp_amd_batch *b = nullptr;
     RCCHK(icp_amd_batch_create(&b, env_int("ICP_AMD_DEVICE", 0), batch, n, m));
     int rc = icp_amd_batch_upload(b, P, Q);

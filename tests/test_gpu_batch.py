@@ -114,3 +114,42 @@ def test_cli_batch_argument(tmp_path):
     assert np.abs(got - want).max() < 1e-4
     r = subprocess.run([exe, "P.txt", "Q.txt", "4", "-batch", "7"], cwd=tmp_path, capture_output=True, text=True, timeout=120)
     assert r.returncode != 0 and "batch count must divide" in r.stderr
+
+
+def test_run_batch_takes_clouds_of_any_size(tmp_path):
+    """icp_amd_run_batch beyond the on-chip limits of the batch kernel (n <= 2048, m <= 4096): the registrations run through
+    ordinary engines, several at a time on their own host threads -- each with exactly the results of icp_amd_run; and the
+    executable's `-batch count` form accepts such files too."""
+    import os
+    import subprocess
+    from conftest import ROOT
+    rng = np.random.RandomState(3)
+    b, n, m = 7, 3000, 5000
+    Ps, Qs = [], []
+    for k in range(b):
+        P, Q = synth.make_pair(n, m, seed=300 + k)
+        Ps.append(P); Qs.append(Q)
+    P, Q = np.stack(Ps), np.stack(Qs)
+    d = icp_amd.run_batch(P, Q, 4)
+    for k in range(b):
+        want, tr = icp_amd.icp_gpu_optimized(P[k], Q[k], 4, trace=True)
+        assert np.array_equal(d["P_out"][k], want), k
+        assert np.array_equal(d["idx"][k], tr["idx"][-1]) and np.array_equal(d["R"][k], tr["R"][-1]) and np.array_equal(d["t"][k], tr["t"][-1])
+        assert d["rms"][k] == tr["rms"][-1]
+    # small clouds still take the batch kernel
+    Pb, Qb = synth.make_batch(5, 300)
+    d2, d3 = icp_amd.run_batch(Pb, Qb, 3), icp_amd.icp_gpu_batch(Pb, Qb, 3)
+    assert np.array_equal(d2["P_out"], d3["P_out"]) and np.array_equal(d2["idx"], d3["idx"])
+    # the executable: two concatenated 2500-point clouds per file
+    Pc, Qc = P[:2, :2500].reshape(-1, 3), Q[:2, :2500].reshape(-1, 3)
+    for name, A in (("P.txt", Pc), ("Q.txt", Qc)):
+        with open(tmp_path / name, "w") as f:
+            f.write("Points_0,Points_1,Points_2\n")
+            for r in A:
+                f.write("%.17g,%.17g,%.17g\n" % tuple(r))
+    r = subprocess.run([os.path.join(ROOT, "bin", "GPUICP"), "P.txt", "Q.txt", "3", "-batch", "2"], cwd=tmp_path, capture_output=True,
+                       text=True, timeout=120, env=dict(os.environ, ICP_AMD_RESULT_FILE=str(tmp_path / "out.npy")))
+    assert r.returncode == 0, r.stderr
+    out, _ = icp_amd.read_cloud(tmp_path / "out.npy")
+    for k in range(2):
+        assert np.array_equal(out[k * 2500:(k + 1) * 2500], icp_amd.icp_gpu_optimized(Pc[k * 2500:(k + 1) * 2500], Qc[k * 2500:(k + 1) * 2500], 3)), k

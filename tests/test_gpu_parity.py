@@ -292,6 +292,27 @@ def test_released_device_memory_is_reused_and_can_be_trimmed():
     assert icp_amd.cache_trim() > 0
 
 
+def test_nothing_relies_on_fresh_or_stale_device_memory():
+    """ICP_AMD_CACHE_POISON=1 hands every device block out filled with the 32-bit pattern 3 (a small valid-looking index, a
+    denormal as a double).  A few whole-path cases in a child process: all variants, a replaced target, batch mode."""
+    import sys
+    code = (
+        "import numpy as np, icp_amd, sys; sys.path.insert(0, %r); from conftest import golden; from icp_amd import synth\n"
+        "for name in ('cow_tr1', 'syn3k_4k', 'lattice'):\n"
+        "    g = golden(name)\n"
+        "    for s in ('auto', 'f32', 'fma', 'exact', 'grid'):\n"
+        "        e = icp_amd.Engine(search=s); e.set_target(g['Q']); e.set_source(g['P']); e.iterate(int(g['iters']))\n"
+        "        assert np.array_equal(e.get_last()['idx'], g['idx'][-1]), (name, s)\n"
+        "        e.set_target(g['Q'][: len(g['Q']) // 2]); e.iterate(1); e.close()\n"
+        "P, Q = synth.make_batch(4, 500)\n"
+        "a = icp_amd.icp_gpu_batch(P, Q, 3)['P_out']\n"
+        "for k in range(4): assert np.array_equal(a[k], icp_amd.icp_gpu_optimized(P[k], Q[k], 3)), k\n"
+        "print('poison ok')\n" % os.path.join(ROOT, "tests"))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=200,
+                       env=dict(os.environ, ICP_AMD_CACHE_POISON="1", PYTHONPATH=ROOT))
+    assert r.returncode == 0 and "poison ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
 def test_concurrent_registrations_from_several_threads():
     """The library keeps no hidden global state between engines: registrations running at the same time on four host
     threads (ctypes releases the GIL; each call has its own engine and stream, they share the device-memory cache and the
