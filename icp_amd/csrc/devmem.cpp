@@ -7,9 +7,12 @@
 // size -- the next registration of a similar cloud allocates nothing.
 //
 // dfree() keeps hipFree's contract: it waits for the block's device to go idle before the block can be reused, so a
-// caller may release memory that kernels it has launched are still reading, exactly as with hipFree.  (A release that
-// waits for the caller's stream only was tried for the batch of engines on several host threads: three times the
-// throughput at four threads, a GPU memory fault at eight, cause not found -- the device-wide wait stays.)
+// caller may release memory that kernels it has launched are still reading, exactly as with hipFree.  dfree_on(p, s) is
+// for blocks that only work on stream s has touched (the temporaries of a target set-up, a grid): it waits for s alone,
+// so engines driven by other host threads keep running -- a batch of registrations on eight threads runs at twice the
+// rate.  (Its first version faulted: the overflow counters of the grid search were cleared with hipMemset, i.e. on the
+// null stream, which is not ordered with the engines' non-blocking streams; the device-wide wait of every release had been
+// hiding that.  Everything the library clears is now cleared on the stream that uses it.)
 #include "kernels.h"
 
 #include <stdlib.h>
@@ -115,7 +118,11 @@ static hipError_t dmalloc_raw(void **p, size_t bytes)
     return hipSuccess;
 }
 
-hipError_t dfree(void *p)
+static hipError_t release(void *p, bool whole_device, hipStream_t s);
+hipError_t dfree(void *p) { return release(p, true, nullptr); }
+hipError_t dfree_on(void *p, hipStream_t s) { return release(p, false, s); }
+
+static hipError_t release(void *p, bool whole_device, hipStream_t s)
 {
     if (!p) return hipSuccess;
     Block b{p, 0, -1};
@@ -130,7 +137,7 @@ hipError_t dfree(void *p)
     int cur = 0;
     (void)hipGetDevice(&cur);
     if (cur != b.dev) (void)hipSetDevice(b.dev);
-    const hipError_t e = hipDeviceSynchronize();
+    const hipError_t e = whole_device ? hipDeviceSynchronize() : hipStreamSynchronize(s);
     if (cur != b.dev) (void)hipSetDevice(cur);
     if (e != hipSuccess) { (void)hipFree(p); return e; }
     std::lock_guard<std::mutex> lk(g_mu);

@@ -287,7 +287,7 @@ extern "C" int icp_amd_set_target(icp_amd_engine *e, const double *Q, size_t m)
     unsigned long long bits = 0;
     if (er == hipSuccess) er = hipMemcpyAsync(&bits, e->qmax2_dev, sizeof bits, hipMemcpyDeviceToHost, e->stream);
     if (er == hipSuccess) er = hipStreamSynchronize(e->stream);
-    (void)dfree(part);
+    (void)dfree_on(part, e->stream);
     HIPCHK(er);
     double qmax2;
     memcpy(&qmax2, &bits, sizeof qmax2);
@@ -428,7 +428,7 @@ static int prepare_grid_source(icp_amd_engine *e)
     e->order_ok = false;
     e->P.rec = nullptr;
     if (n && wants_grid(e)) {
-        if (!e->gscratch.list) HIPCHK(grid_scratch_alloc(n_pad, &e->gscratch));
+        if (!e->gscratch.list) HIPCHK(grid_scratch_alloc(e->stream, n_pad, &e->gscratch));
         if (!e->grid_out) HIPCHK(dmalloc(&e->grid_out, n_pad * sizeof(double2)));
         if (env_int("ICP_AMD_GRID_SRCREC", 1)) {
             if (!e->p_rec) HIPCHK(dmalloc(&e->p_rec, 2 * n_pad * sizeof(double4)));
@@ -467,7 +467,7 @@ extern "C" int icp_amd_set_source(icp_amd_engine *e, const double *P, size_t n)
         e->p_store = nullptr; e->idx = nullptr; e->order = nullptr; e->n_pad = 0;
         HIPCHK(dmalloc(&e->p_store, 3 * n_pad * sizeof(double)));
         HIPCHK(dmalloc(&e->idx, n_pad * sizeof(uint32_t)));
-        HIPCHK(hipMemset(e->idx, 0xFF, n_pad * sizeof(uint32_t)));
+        HIPCHK(hipMemsetAsync(e->idx, 0xFF, n_pad * sizeof(uint32_t), e->stream));   // ordered with the kernels, like everything else
         e->n_pad = n_pad;
         e->P = Soa3{e->p_store, e->p_store + n_pad, e->p_store + 2 * n_pad};
     }
@@ -945,8 +945,6 @@ extern "C" int icp_amd_run_multi(const double *P, size_t n, const double *Q, siz
         RCCHK(require_device(r.dev[g]));
         HIPCHK(dmalloc(&r.cov[g], (size_t)G * cpr * kCovW * sizeof(double)));
         HIPCHK(dmalloc(&r.cen[g], (size_t)G * cpr * kCenW * sizeof(double)));
-        HIPCHK(hipMemset(r.cov[g], 0, (size_t)G * cpr * kCovW * sizeof(double)));
-        HIPCHK(hipMemset(r.cen[g], 0, (size_t)G * cpr * kCenW * sizeof(double)));
         icp_amd_options opt;
         icp_amd_default_options(&opt);
         opt.device = r.dev[g];
@@ -958,6 +956,9 @@ extern "C" int icp_amd_run_multi(const double *P, size_t n, const double *Q, siz
         icp_amd_engine *e = nullptr;
         RCCHK(icp_amd_create(&e, &opt));
         r.eng.push_back(e);
+        // on the engine's own stream: ordered before everything that engine (and the exchange on its stream) does with them
+        HIPCHK(hipMemsetAsync(r.cov[g], 0, (size_t)G * cpr * kCovW * sizeof(double), e->stream));
+        HIPCHK(hipMemsetAsync(r.cen[g], 0, (size_t)G * cpr * kCenW * sizeof(double), e->stream));
     }
     if (r.by_copies) {
         r.ready.assign(G, nullptr);
@@ -1147,7 +1148,7 @@ extern "C" int icp_amd_run_batch(const double *P, const double *Q, size_t batch,
         // instead, a few at a time (one host thread, engine and stream each; the device-memory cache makes their set-up
         // cheap), so that small launches of different registrations overlap on the device.  Same results as icp_amd_run.
         RCCHK(require_device(env_int("ICP_AMD_DEVICE", 0)));
-        const size_t workers = std::min<size_t>(batch, (size_t)std::max(1, std::min(env_int("ICP_AMD_BATCH_WORKERS", 4), 64)));
+        const size_t workers = std::min<size_t>(batch, (size_t)std::max(1, std::min(env_int("ICP_AMD_BATCH_WORKERS", 8), 64)));
         std::vector<int> rcs(workers, ICP_AMD_OK);
         std::vector<std::string> errs(workers);
         auto work = [&](size_t w) {
@@ -1247,7 +1248,7 @@ extern "C" int icp_amd_correspondences(const double *P, size_t n, const double P
     if (grid) {
         q_splits = 1;
         struct ScratchHolder { GridScratch sc; ~ScratchHolder() { grid_scratch_free(&sc); } } sh;
-        HIPCHK(grid_scratch_alloc(n, &sh.sc));
+        HIPCHK(grid_scratch_alloc(s, n, &sh.sc));
         HIPCHK(grec.alloc(n_pad * sizeof(double2)));
         HIPCHK(search_grid(s, dP, n, pc.as<double>(), gh.g, dQ, m, nullptr, nullptr, &sh.sc, grec.as<double2>()));
         HIPCHK(hipStreamSynchronize(s));   // the scratch is released on scope exit

@@ -478,9 +478,15 @@ hipError_t grid_warmup(hipStream_t s)
 void grid_free(Grid *g)
 {
     if (!g) return;
-    if (g->start) (void)dfree(g->start);
-    if (g->perm) (void)dfree(g->perm);
-    if (g->rec) (void)dfree(g->rec);
+    if (g->on_stream) {
+        if (g->start) (void)dfree_on(g->start, g->stream);
+        if (g->perm) (void)dfree_on(g->perm, g->stream);
+        if (g->rec) (void)dfree_on(g->rec, g->stream);
+    } else {
+        if (g->start) (void)dfree(g->start);
+        if (g->perm) (void)dfree(g->perm);
+        if (g->rec) (void)dfree(g->rec);
+    }
     *g = Grid{};
 }
 
@@ -535,6 +541,8 @@ static hipError_t grid_sort(hipStream_t s, Soa3 Qz, size_t m, double per_cell, b
 {
     grid_free(g);
     if (m == 0 || m > 0xFFFFFFF0u) return hipErrorInvalidValue;
+    g->stream = s;   // everything that touches this grid is enqueued on s: releasing it waits for s only
+    g->on_stream = true;
     hipError_t e;
     unsigned long long *bb = nullptr;
     uint32_t *cell = nullptr, *counts = nullptr, *cursor = nullptr, *block_sums = nullptr;
@@ -587,7 +595,7 @@ static hipError_t grid_sort(hipStream_t s, Soa3 Qz, size_t m, double per_cell, b
             if (avg <= 2.0 * per_cell) break;
             double f = sqrt(per_cell / avg);
             h_scale *= f < 0.25 ? 0.25 : f;
-            (void)dfree(counts);
+            (void)dfree_on(counts, s);
             counts = nullptr;
         }
     }
@@ -614,11 +622,11 @@ static hipError_t grid_sort(hipStream_t s, Soa3 Qz, size_t m, double per_cell, b
     g->ok = true;
 #undef GRID_TRY
 done:
-    if (bb) (void)dfree(bb);
-    if (cell) (void)dfree(cell);
-    if (counts) (void)dfree(counts);
-    if (cursor) (void)dfree(cursor);
-    if (block_sums) (void)dfree(block_sums);
+    if (bb) (void)dfree_on(bb, s);
+    if (cell) (void)dfree_on(cell, s);
+    if (counts) (void)dfree_on(counts, s);
+    if (cursor) (void)dfree_on(cursor, s);
+    if (block_sums) (void)dfree_on(block_sums, s);
     if (e != hipSuccess) grid_free(g);
     return e;
 }
@@ -682,7 +690,7 @@ hipError_t search_grid(hipStream_t s, Soa3 P, size_t n, const double *pc, const 
     return hipGetLastError();
 }
 
-hipError_t grid_scratch_alloc(size_t n, GridScratch *sc)
+hipError_t grid_scratch_alloc(hipStream_t s, size_t n, GridScratch *sc)
 {
     grid_scratch_free(sc);
     // what one lane may walk on its own before it hands its point to the overflow kernel (tunable for tests)
@@ -690,7 +698,7 @@ hipError_t grid_scratch_alloc(size_t n, GridScratch *sc)
     sc->eval_cap = getenv("ICP_AMD_GRID_EVALCAP") ? atoi(getenv("ICP_AMD_GRID_EVALCAP")) : 768;
     sc->defer_always = getenv("ICP_AMD_GRID_DEFER") && !strcmp(getenv("ICP_AMD_GRID_DEFER"), "always");
     hipError_t e = dmalloc(&sc->count2, 2 * sizeof(uint32_t));
-    if (e == hipSuccess) e = hipMemset(sc->count2, 0, 2 * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMemsetAsync(sc->count2, 0, 2 * sizeof(uint32_t), s);   // s: the stream the searches will run on
     if (e == hipSuccess) e = dmalloc(&sc->list, (n ? n : 1) * sizeof(uint32_t));
     if (e == hipSuccess) e = hipHostMalloc((void **)&sc->host_mem, sizeof(uint32_t), hipHostMallocMapped);
     if (e == hipSuccess) {

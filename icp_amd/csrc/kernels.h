@@ -22,6 +22,9 @@ constexpr size_t kSplitGran = 64;  // target splits are whole multiples of this 
 hipError_t dmalloc_bytes(void **p, size_t bytes);
 template <class T> inline hipError_t dmalloc(T **p, size_t bytes) { return dmalloc_bytes((void **)p, bytes); }
 hipError_t dfree(void *p);
+// same, for a block that only work enqueued on stream `s` has touched: waits for that stream instead of the whole device,
+// so engines on other streams keep running (a batch of registrations on several host threads)
+hipError_t dfree_on(void *p, hipStream_t s);
 void dcache_trim();      // give every kept block back to the driver
 size_t dcache_held();    // bytes kept
 
@@ -89,6 +92,8 @@ struct Grid {
     uint32_t *perm = nullptr;    // m: original index of each sorted target
     double4 *rec = nullptr;      // m: sorted targets as {x, y, z, original index (integer bit pattern)}
     bool ok = false;             // false: the cloud has non-finite coordinates, use a brute-force variant
+    hipStream_t stream = nullptr;   // the stream the grid was built on and is searched on (grid_free waits for it)
+    bool on_stream = false;
 };
 // Builds the grid of Qz[0, m) (allocates; synchronises the stream).  Non-finite coordinates: success with ok = false.
 hipError_t grid_build(hipStream_t s, Soa3 Qz, size_t m, Grid *g);
@@ -106,7 +111,7 @@ struct GridScratch {
     int row_cap = 64, eval_cap = 768;       // rows of cells / targets one lane walks alone (read from the environment at allocation)
     int defer_always = 0;                   // 1: hand over every box above the caps (tests); 0: only when most of the wave would idle
 };
-hipError_t grid_scratch_alloc(size_t n, GridScratch *sc);
+hipError_t grid_scratch_alloc(hipStream_t s, size_t n, GridScratch *sc);   // s: the stream the searches will run on
 void grid_scratch_free(GridScratch *sc);
 // order: optional processing order of the source rows (grid_order), a permutation of [0, n); results do not depend on it.
 // sc == nullptr: every lane finishes its own point, however large its box.

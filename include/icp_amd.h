@@ -176,7 +176,7 @@ int icp_amd_batch_download(icp_amd_batch *b, double *P_out, double *R, double *t
 int icp_amd_batch_destroy(icp_amd_batch *b);
 /* One-shot convenience over the five calls above.  Clouds beyond the limits of the one-workgroup-per-registration kernel
  * (n <= 2048, m <= 4096) are not an error here: they are registered through ordinary engines, ICP_AMD_BATCH_WORKERS
- * (default 4) registrations at a time on their own host threads and streams, with the results of icp_amd_run. */
+ * (default 8) registrations at a time on their own host threads and streams, with the results of icp_amd_run. */
 int icp_amd_run_batch(const double *P, const double *Q, size_t batch, size_t n, size_t m, unsigned iters,
                       double *P_out, double *R, double *t, int32_t *idx, double *rms);
 
