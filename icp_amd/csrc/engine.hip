@@ -178,7 +178,9 @@ struct icp_amd_engine {
     unsigned search_launches = 0;
 };
 
-static void free_dev(void *p) { if (p) (void)dfree(p); }
+// a block of engine e: only work enqueued on e->stream has touched it, so the release waits for that stream alone and
+// engines driven by other host threads keep running
+static void free_dev(icp_amd_engine *e, void *p) { if (p) (void)dfree_on(p, e->stream); }
 
 static int env_int(const char *name, int dflt)
 {
@@ -225,13 +227,13 @@ extern "C" int icp_amd_destroy(icp_amd_engine *e)
     (void)hipSetDevice(e->opt.device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     for (hipEvent_t ev : e->ev) (void)hipEventDestroy(ev);
-    free_dev(e->q_store); free_dev(e->q_rec); free_dev(e->qc); free_dev(e->qrec); free_dev(e->qmax2_dev); free_dev(e->p_store); free_dev(e->pc); free_dev(e->stage);
-    free_dev(e->keys); free_dev(e->idxs); free_dev(e->idx); free_dev(e->rec);
+    free_dev(e, e->q_store); free_dev(e, e->q_rec); free_dev(e, e->qc); free_dev(e, e->qrec); free_dev(e, e->qmax2_dev); free_dev(e, e->p_store); free_dev(e, e->pc); free_dev(e, e->stage);
+    free_dev(e, e->keys); free_dev(e, e->idxs); free_dev(e, e->idx); free_dev(e, e->rec);
     grid_free(&e->grid);
-    free_dev(e->order);
+    free_dev(e, e->order);
     grid_scratch_free(&e->gscratch);
-    free_dev(e->p_rec); free_dev(e->grid_out);
-    if (e->own_part) { free_dev(e->cov_part); free_dev(e->cen_part); }
+    free_dev(e, e->p_rec); free_dev(e, e->grid_out);
+    if (e->own_part) { free_dev(e, e->cov_part); free_dev(e, e->cen_part); }
     if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
     return ICP_AMD_OK;
@@ -240,7 +242,7 @@ extern "C" int icp_amd_destroy(icp_amd_engine *e)
 static int ensure_stage(icp_amd_engine *e, size_t rows)
 {
     if (rows <= e->stage_rows) return ICP_AMD_OK;
-    free_dev(e->stage);
+    free_dev(e, e->stage);
     e->stage = nullptr;
     e->stage_rows = 0;
     HIPCHK(dmalloc(&e->stage, rows * 3 * sizeof(double)));
@@ -261,7 +263,7 @@ extern "C" int icp_amd_set_target(icp_amd_engine *e, const double *Q, size_t m)
     HIPCHK(hipSetDevice(e->opt.device));
     const size_t m_pad = round_up(m, kPadRows);
     if (m_pad != e->m_pad) {
-        free_dev(e->q_store); free_dev(e->qrec); free_dev(e->q_rec);
+        free_dev(e, e->q_store); free_dev(e, e->qrec); free_dev(e, e->q_rec);
         e->q_store = nullptr; e->qrec = nullptr; e->q_rec = nullptr;
         e->m_pad = 0;
         HIPCHK(dmalloc(&e->q_store, 3 * m_pad * sizeof(double)));
@@ -396,7 +398,7 @@ static int ensure_split_buffers(icp_amd_engine *e)
 {
     const size_t need = (size_t)e->q_splits * e->n_pad;
     if (need > e->split_cap) {
-        free_dev(e->keys); free_dev(e->idxs);
+        free_dev(e, e->keys); free_dev(e, e->idxs);
         e->keys = nullptr; e->idxs = nullptr; e->split_cap = 0;
         HIPCHK(dmalloc(&e->keys, need * sizeof(double)));
         HIPCHK(dmalloc(&e->idxs, need * sizeof(uint32_t)));
@@ -460,9 +462,9 @@ extern "C" int icp_amd_set_source(icp_amd_engine *e, const double *P, size_t n)
     HIPCHK(hipSetDevice(e->opt.device));
     const size_t n_pad = round_up(n ? n : 1, kPadRows);
     if (n_pad != e->n_pad) {
-        free_dev(e->p_store); free_dev(e->idx); free_dev(e->order);
+        free_dev(e, e->p_store); free_dev(e, e->idx); free_dev(e, e->order);
         grid_scratch_free(&e->gscratch);
-        free_dev(e->p_rec); free_dev(e->grid_out);
+        free_dev(e, e->p_rec); free_dev(e, e->grid_out);
         e->p_rec = nullptr; e->grid_out = nullptr;
         e->p_store = nullptr; e->idx = nullptr; e->order = nullptr; e->n_pad = 0;
         HIPCHK(dmalloc(&e->p_store, 3 * n_pad * sizeof(double)));
@@ -477,12 +479,12 @@ extern "C" int icp_amd_set_source(icp_amd_engine *e, const double *P, size_t n)
     e->chunks_local = (n + kChunk - 1) / kChunk;
     const size_t total = cpr * (size_t)world;
     if (e->opt.cov_gather && e->opt.cen_gather) {   // caller-owned exchange buffers (required when world > 1)
-        if (e->own_part) { free_dev(e->cov_part); free_dev(e->cen_part); }
+        if (e->own_part) { free_dev(e, e->cov_part); free_dev(e, e->cen_part); }
         e->cov_part = e->opt.cov_gather;
         e->cen_part = e->opt.cen_gather;
         e->own_part = false;
     } else if (total != e->total_chunks || !e->own_part) {
-        if (e->own_part) { free_dev(e->cov_part); free_dev(e->cen_part); }
+        if (e->own_part) { free_dev(e, e->cov_part); free_dev(e, e->cen_part); }
         e->cov_part = e->cen_part = nullptr;
         HIPCHK(dmalloc(&e->cov_part, total * kCovW * sizeof(double)));
         HIPCHK(dmalloc(&e->cen_part, total * kCenW * sizeof(double)));
@@ -1040,8 +1042,10 @@ extern "C" int icp_amd_batch_destroy(icp_amd_batch *b)
 {
     if (!b) return ICP_AMD_OK;
     (void)hipSetDevice(b->device);
-    if (b->stream) { (void)hipStreamSynchronize(b->stream); (void)hipStreamDestroy(b->stream); }
-    free_dev(b->P_in); free_dev(b->Q_in); free_dev(b->P_out); free_dev(b->rec); free_dev(b->idx);
+    if (b->stream) (void)hipStreamSynchronize(b->stream);
+    for (void *p : {(void *)b->P_in, (void *)b->Q_in, (void *)b->P_out, (void *)b->rec, (void *)b->idx})
+        if (p) (void)(b->stream ? dfree_on(p, b->stream) : dfree(p));   // only this object's stream has touched them
+    if (b->stream) (void)hipStreamDestroy(b->stream);
     delete b;
     return ICP_AMD_OK;
 }
