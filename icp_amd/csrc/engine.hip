@@ -132,6 +132,9 @@ struct icp_amd_engine {
     double qmax = 0.0;          // sqrt(max |q|^2) of the centred target
     bool f32_ok = false;        // the fp32 error bound is meaningful for this target's range
     int mfma_g = 0;             // F32 on the matrix pipe: 32-row source groups per wave (0: packed-VALU kernel)
+    bool mfma16 = false;        // ... on the fp16 K = 16 MFMA (operands in two fp16 pieces), needs qrec16
+    void *qrec16 = nullptr;     // 2 * m_pad 16-byte halves of the fp16 target records (built when that filter is selected)
+    bool qrec16_ok = false;
     Grid grid;                  // uniform grid over Qz (search variant GRID); built on first use per target
     bool grid_built = false;
     uint32_t *order = nullptr;  // n_pad: source rows in spatial order (GRID), valid when order_ok
@@ -228,7 +231,7 @@ extern "C" int icp_amd_destroy(icp_amd_engine *e)
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     for (hipEvent_t ev : e->ev) (void)hipEventDestroy(ev);
     free_dev(e, e->q_store); free_dev(e, e->q_rec); free_dev(e, e->qc); free_dev(e, e->qrec); free_dev(e, e->qmax2_dev); free_dev(e, e->p_store); free_dev(e, e->pc); free_dev(e, e->stage);
-    free_dev(e, e->keys); free_dev(e, e->idxs); free_dev(e, e->idx); free_dev(e, e->rec);
+    free_dev(e, e->keys); free_dev(e, e->idxs); free_dev(e, e->idx); free_dev(e, e->rec); free_dev(e, e->qrec16);
     grid_free(&e->grid);
     free_dev(e, e->order);
     grid_scratch_free(&e->gscratch);
@@ -263,8 +266,8 @@ extern "C" int icp_amd_set_target(icp_amd_engine *e, const double *Q, size_t m)
     HIPCHK(hipSetDevice(e->opt.device));
     const size_t m_pad = round_up(m, kPadRows);
     if (m_pad != e->m_pad) {
-        free_dev(e, e->q_store); free_dev(e, e->qrec); free_dev(e, e->q_rec);
-        e->q_store = nullptr; e->qrec = nullptr; e->q_rec = nullptr;
+        free_dev(e, e->q_store); free_dev(e, e->qrec); free_dev(e, e->q_rec); free_dev(e, e->qrec16);
+        e->q_store = nullptr; e->qrec = nullptr; e->q_rec = nullptr; e->qrec16 = nullptr;
         e->m_pad = 0;
         HIPCHK(dmalloc(&e->q_store, 3 * m_pad * sizeof(double)));
         HIPCHK(dmalloc(&e->q_rec, m_pad * sizeof(double4)));
@@ -295,6 +298,7 @@ extern "C" int icp_amd_set_target(icp_amd_engine *e, const double *Q, size_t m)
     memcpy(&qmax2, &bits, sizeof qmax2);
     e->f32_ok = (qmax2 == qmax2) && qmax2 > 1e-30 && qmax2 < 1e30;
     e->qmax = e->f32_ok ? sqrt(qmax2) : 0.0;
+    e->qrec16_ok = false;
     e->have_target = true;
     grid_free(&e->grid);
     e->grid_built = false;
@@ -332,8 +336,13 @@ static int requested_variant(const icp_amd_engine *e)
 static int mfma_groups()
 {
     const int v = env_int("ICP_AMD_MFMA", 0);
+    if (v == 16) {   // the fp16 K = 16 instruction; groups from ICP_AMD_MFMA_G
+        const int g = env_int("ICP_AMD_MFMA_G", 4);
+        return (g == 2 || g == 4 || g == 8) ? g : 4;
+    }
     return (v == 2 || v == 4 || v == 8) ? v : 0;
 }
+static bool mfma_fp16() { return env_int("ICP_AMD_MFMA", 0) == 16; }
 
 // AUTO searches on the grid from this many targets on: the grid saves 18 us per iteration at 1000 targets (36 at 2000)
 // and costs about 250 us more to set up (tools/tiny_probe.py), so it pays from roughly 15 iterations on here.
@@ -376,6 +385,7 @@ static void choose_geometry(icp_amd_engine *e)
     if (want < 2 * cus) want = 2 * cus;
     if (want > 64 * cus) want = 64 * cus;
     e->mfma_g = f32 ? mfma_groups() : 0;
+    e->mfma16 = e->mfma_g && mfma_fp16();
     const size_t xblocks = e->n_pad / (e->mfma_g ? (size_t)search_mfma_rows_per_workgroup(e->mfma_g) : (size_t)kWG * ppl);
     size_t splits = (want + xblocks - 1) / xblocks;
     if (splits > 1024) splits = 1024;
@@ -583,7 +593,15 @@ extern "C" int icp_amd_step_search(icp_amd_engine *e)
         if (grid)
             HIPCHK(search_grid(e->stream, e->P, e->n, e->pc, e->grid, e->Qz, e->m, seed ? e->idx : nullptr,
                                e->order_ok ? e->order : nullptr, &e->gscratch, e->grid_out));
-        else if (e->variant == kF32 && e->mfma_g)
+        else if (e->variant == kF32 && e->mfma16) {
+            if (!e->qrec16_ok) {   // the fp16 records of this target, on first use
+                if (!e->qrec16) HIPCHK(dmalloc(&e->qrec16, 32 * e->m_pad));
+                HIPCHK(build_qrec16(e->stream, e->Qz, e->m, e->m_pad, e->qmax, e->qrec16));
+                e->qrec16_ok = true;
+            }
+            HIPCHK(search_mfma16(e->stream, e->mfma_g, e->P, e->n_pad, e->pc, e->Qz, e->qrec16, e->qmax, e->m, e->m_pad, splits,
+                                 seed ? e->idx : nullptr, e->keys, e->idxs));
+        } else if (e->variant == kF32 && e->mfma_g)
             HIPCHK(search_mfma(e->stream, e->mfma_g, e->P, e->n_pad, e->pc, e->Qz, e->qrec, e->qmax, e->m, e->m_pad, splits,
                                seed ? e->idx : nullptr, e->keys, e->idxs));
         else if (e->variant == kF32)
@@ -1267,7 +1285,14 @@ extern "C" int icp_amd_correspondences(const double *P, size_t n, const double P
         double qmax2;
         memcpy(&qmax2, &bits, sizeof qmax2);
         if ((qmax2 == qmax2) && qmax2 > 1e-30 && qmax2 < 1e30) {
-            if (mfma_groups())
+            if (mfma_fp16()) {
+                DevBuf rec16;
+                HIPCHK(rec16.alloc(32 * m_pad));
+                HIPCHK(build_qrec16(s, dQ, m, m_pad, sqrt(qmax2), rec16.p));
+                HIPCHK(search_mfma16(s, mfma_groups(), dP, n_pad, pc.as<double>(), dQ, rec16.p, sqrt(qmax2), m, m_pad, q_splits, nullptr,
+                                     keys.as<double>(), idxs.as<uint32_t>()));
+                HIPCHK(hipStreamSynchronize(s));   // rec16 is released on scope exit
+            } else if (mfma_groups())
                 HIPCHK(search_mfma(s, mfma_groups(), dP, n_pad, pc.as<double>(), dQ, qrec.p, sqrt(qmax2), m, m_pad, q_splits, nullptr,
                                    keys.as<double>(), idxs.as<uint32_t>()));
             else

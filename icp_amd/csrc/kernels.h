@@ -75,6 +75,12 @@ int search_mfma_rows_per_workgroup(int groups);
 hipError_t search_mfma(hipStream_t s, int groups, Soa3 P, size_t n_pad, const double *pc, Soa3 Qz, const void *qrec, double qmax,
                        size_t m, size_t m_pad, int q_splits, const uint32_t *idx_prev, double *out_key, uint32_t *out_idx);
 
+// The filter on v_mfma_f32_32x32x16_f16 (search_mfma.hip): every operand in two fp16 pieces after a power-of-two scaling.
+// rec16: 32 bytes per target (2 * m_pad 16-byte halves) built by build_qrec16 from the centred target and qmax.
+hipError_t build_qrec16(hipStream_t s, Soa3 Qz, size_t m, size_t m_pad, double qmax, void *rec16);
+hipError_t search_mfma16(hipStream_t s, int groups, Soa3 P, size_t n_pad, const double *pc, Soa3 Qz, const void *rec16, double qmax,
+                         size_t m, size_t m_pad, int q_splits, const uint32_t *idx_prev, double *out_key, uint32_t *out_idx);
+
 // Uniform grid over the centred target cloud (grid.hip): same correspondences as the brute-force kernels, found by
 // evaluating only the targets in the cells a query's search box touches.
 // one empty launch from grid.hip: loads that translation unit's code object (icp_amd_init)

@@ -35,6 +35,7 @@
 #include "kernels.h"
 #include "search_common.h"
 
+#include <math.h>
 #include <stdlib.h>
 
 namespace icpk {
@@ -152,6 +153,225 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(2))) void s
             out_idx[o + g * 32u] = bj[g];
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// the same filter on v_mfma_f32_32x32x16_f16: one MFMA per 32 targets x 32 source rows
+// ------------------------------------------------------------------------------------------------
+// The K = 16 half-precision MFMA of gfx950 runs at 16 times the fp32 matrix rate, and K = 16 is room to carry every
+// operand in TWO fp16 pieces (hi + lo, 22 bits) -- after scaling both clouds by a power of two sigma that puts the largest
+// coordinate at 2^6..2^7, far from fp16's overflow and with the lo pieces mostly above its subnormals:
+//     s' = sigma^2 (|q|^2 - 2 p.q) = sum over c of (Th + Tl)(Ph + Pl) + (W0 + W1 + W2),   T = -2 sigma q_c, P = sigma p_c, W = sigma^2 |q|^2
+// = 15 products (the 16th slot is 0): half 0 of the wave carries x and y, half 1 carries z and the three pieces of W
+// against ones.  Every product of two fp16 values is exact in fp32, so the error is the pieces' truncation
+// (<= 2^-22 relative each, or 2^-14 absolute for a piece in the subnormal range should the pipe flush it) plus the fp32
+// accumulation of 16 terms:
+//     |s'_computed - s'| <= 2^-20 (|P| Tmax + Wmax) + 2^-13 (|P| + Tmax) + 2^-12 =: E'    (all in scaled units),
+// the first term being the standard bound for 16 sequential fp32 additions (4 times what a pipe that rounds once per four
+// products would need).  Everything else is the fp32 filter: threshold sigma^2 (bd (1 + 2^-50) - |p|^2 (1 - 2^-50)) + E', exact
+// re-evaluation of every block that trips it.  A source row whose scaled coordinates leave fp16's range multiplies by
+// zero instead and takes the exact path on every block.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+struct __attribute__((aligned(16))) Half8 { _Float16 v[8]; };
+
+__device__ __forceinline__ void split16(double v, _Float16 &hi, _Float16 &lo)
+{
+    hi = (_Float16)(float)v;
+    lo = (_Float16)(float)(v - (double)(float)hi);
+}
+
+// rec16[0 .. m_pad) = half 0 of every target {Txh,Txh,Txl,Txl,Tyh,Tyh,Tyl,Tyl}, rec16[m_pad .. 2 m_pad) = half 1
+// {Tzh,Tzh,Tzl,Tzl,W0,W1,W2,0}; pad targets: W0 = +inf
+__global__ __launch_bounds__(kWG) void build_qrec16_kernel(const double *__restrict__ qx, const double *__restrict__ qy,
+                                                           const double *__restrict__ qz, size_t m, size_t m_pad, double sigma,
+                                                           Half8 *__restrict__ rec16)
+{
+    const size_t i = (size_t)blockIdx.x * kWG + threadIdx.x;
+    if (i >= m_pad) return;
+    Half8 a, b;
+    for (int k = 0; k < 8; ++k) a.v[k] = b.v[k] = (_Float16)0.0f;
+    if (i < m) {
+        const double x = qx[i], y = qy[i], z = qz[i];
+        _Float16 h, l;
+        split16(-2.0 * sigma * x, h, l); a.v[0] = a.v[1] = h; a.v[2] = a.v[3] = l;
+        split16(-2.0 * sigma * y, h, l); a.v[4] = a.v[5] = h; a.v[6] = a.v[7] = l;
+        split16(-2.0 * sigma * z, h, l); b.v[0] = b.v[1] = h; b.v[2] = b.v[3] = l;
+        const double w = sigma * sigma * ((x * x + y * y) + z * z);
+        const _Float16 w0 = (_Float16)(float)w;
+        const double r1 = w - (double)(float)w0;
+        const _Float16 w1 = (_Float16)(float)r1;
+        const _Float16 w2 = (_Float16)(float)(r1 - (double)(float)w1);
+        b.v[4] = w0; b.v[5] = w1; b.v[6] = w2;
+    } else {
+        b.v[4] = (_Float16)INFINITY;
+    }
+    rec16[i] = a;
+    rec16[m_pad + i] = b;
+}
+
+constexpr int kTileQH = 1024;   // targets per LDS tile (2 x 16 KB)
+constexpr int kRowsH = 64;      // targets between event checks of the fp16 filter = two MFMA blocks (= kSplitGran)
+
+template <int G>
+__global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(2))) void search_mfma16_kernel(
+    const double *__restrict__ px, const double *__restrict__ py, const double *__restrict__ pz, const double *__restrict__ pc,
+    const double *__restrict__ qx, const double *__restrict__ qy, const double *__restrict__ qz, const Half8 *__restrict__ rec16,
+    double qmax, double sigma, double escale, unsigned n_pad, unsigned m, unsigned m_pad, unsigned m_scan, unsigned q_per_split,
+    const uint32_t *__restrict__ idx_prev, double *__restrict__ out_key, uint32_t *__restrict__ out_idx)
+{
+    __shared__ Half8 st[2][kTileQH];
+    const unsigned tid = threadIdx.x;
+    const unsigned lane = tid & 63u, wave = tid >> 6;
+    const unsigned col = lane & 31u, half = lane >> 5;
+    const unsigned base = blockIdx.x * (4u * 32u * G) + wave * (32u * G) + col;
+    const double c0 = pc[0], c1 = pc[1], c2 = pc[2];
+    const unsigned q0 = blockIdx.y * q_per_split;
+    const unsigned q1 = (q0 + q_per_split < m_scan) ? (q0 + q_per_split) : m_scan;
+    const double s2 = sigma * sigma, tmax = 2.0 * sigma * qmax, wmax = s2 * qmax * qmax;
+
+    f16x8 b[G];
+    float ms[G], thr[G];
+    double bd[G], bk[G];
+    uint32_t bj[G], sblk[G];
+    // threshold in scaled units from the exact running bound
+    auto threshold = [&](double bdv, double pn) -> float {
+        const double pl = sigma * sqrt(pn);
+        const double E = escale * (0x1p-20 * (pl * tmax + wmax) + 0x1p-13 * (pl + tmax) + 0x1p-12);
+        const bool usable = pn < 1e30 && pl < 16384.0;
+        return f32_above(usable ? s2 * ((bdv - pn) + (bdv + pn) * 0x1p-50) + E : INFINITY);
+    };
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        const unsigned row = base + g * 32u;
+        const double ax = px[row] - c0, ay = py[row] - c1, az = pz[row] - c2;
+        const double pn = (ax * ax + ay * ay) + az * az;
+        const bool usable = pn < 1e30 && sigma * sqrt(pn) < 16384.0;
+        _Float16 xh, xl, yh, yl, zh, zl;
+        split16(usable ? sigma * ax : 0.0, xh, xl);
+        split16(usable ? sigma * ay : 0.0, yh, yl);
+        split16(usable ? sigma * az : 0.0, zh, zl);
+        const _Float16 one = (_Float16)1.0f, zero = (_Float16)0.0f;
+        const f16x8 b0 = {xh, xl, xh, xl, yh, yl, yh, yl};
+        const f16x8 b1 = {zh, zl, zh, zl, one, one, one, zero};
+        b[g] = half ? b1 : b0;
+        const uint32_t js = idx_prev ? idx_prev[row] : 0xFFFFFFFFu;
+        bd[g] = seed_init<kRowsH>(ax, ay, az, qx, qy, qz, js, m, q0, q1, bk[g], bj[g], sblk[g]);
+        thr[g] = threshold(bd[g], pn);
+        ms[g] = thr[g];
+    }
+    const Half8 *sa = st[half];
+
+    for (unsigned t0 = q0; t0 < q1; t0 += kTileQH) {
+        const int cnt = (q1 - t0 < (unsigned)kTileQH) ? (int)(q1 - t0) : kTileQH;   // multiple of kSplitGran
+        __syncthreads();
+        for (int k = tid; k < cnt; k += kWG) {
+            st[0][k] = rec16[t0 + k];
+            st[1][k] = rec16[(size_t)m_pad + t0 + k];
+        }
+        __syncthreads();
+        // 64 targets between event checks: two MFMA rounds per source group, the operand of the next round already on
+        // its way from LDS while this one is reduced
+        f16x8 a_next = *(const f16x8 *)&sa[col];
+        for (int j0 = 0; j0 < cnt; j0 += kRowsH) {
+            const f16x8 a0 = a_next;
+            const f16x8 a1 = *(const f16x8 *)&sa[j0 + 32 + col];
+            a_next = *(const f16x8 *)&sa[(j0 + kRowsH < cnt ? j0 + kRowsH : 0) + col];
+            f32x16 acc[G];
+            const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int g = 0; g < G; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b[g], zero, 0, 0, 0);
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                float v = ms[g];
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) v = vmin3f(v, acc[g][r], acc[g][r + 1]);
+                ms[g] = v;
+                acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b[g], zero, 0, 0, 0);
+            }
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                float v = ms[g];
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) v = vmin3f(v, acc[g][r], acc[g][r + 1]);
+                ms[g] = v;
+            }
+            const unsigned blk = (t0 + (unsigned)j0) / kRowsH;
+            bool ev = false;
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                if (blk == sblk[g]) ms[g] = thr[g];   // the seed's own block was evaluated exactly by seed_init
+                ev |= (ms[g] < thr[g]);
+            }
+            if (ev) {
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    if (ms[g] < thr[g]) {
+                        const unsigned row = base + g * 32u;
+                        const double ax = px[row] - c0, ay = py[row] - c1, az = pz[row] - c2;
+                        const double pn = (ax * ax + ay * ay) + az * az;
+                        const unsigned jg = t0 + (unsigned)j0;
+                        double dbest;
+                        rescan_block<kRowsH>(ax, ay, az, qx + jg, qy + jg, qz + jg, 0, jg, bd[g], bk[g], bj[g], dbest);
+                        thr[g] = threshold(bd[g], pn);
+                        ms[g] = thr[g];
+                    }
+                }
+            }
+        }
+    }
+    const size_t o = (size_t)blockIdx.y * n_pad + base;
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        const double ok = __shfl_xor(bk[g], 32, 64);
+        const uint32_t oj = __shfl_xor(bj[g], 32, 64);
+        if (ok < bk[g] || (ok == bk[g] && oj < bj[g])) {
+            bk[g] = ok;
+            bj[g] = oj;
+        }
+        if (half == 0) {
+            out_key[o + g * 32u] = bk[g];
+            out_idx[o + g * 32u] = bj[g];
+        }
+    }
+}
+
+// sigma: the power of two that puts qmax (the largest |q| of the centred target) into [2^6, 2^7)
+double search_mfma16_scale(double qmax)
+{
+    int e = 0;
+    (void)frexp(qmax, &e);   // qmax = f * 2^e, f in [0.5, 1)
+    return ldexp(1.0, 7 - e);
+}
+
+hipError_t build_qrec16(hipStream_t s, Soa3 Qz, size_t m, size_t m_pad, double qmax, void *rec16)
+{
+    if (m_pad == 0 || !(qmax > 0.0)) return hipErrorInvalidValue;
+    build_qrec16_kernel<<<(unsigned)((m_pad + kWG - 1) / kWG), kWG, 0, s>>>(Qz.x, Qz.y, Qz.z, m, m_pad, search_mfma16_scale(qmax),
+                                                                           (Half8 *)rec16);
+    return hipGetLastError();
+}
+
+hipError_t search_mfma16(hipStream_t s, int groups, Soa3 P, size_t n_pad, const double *pc, Soa3 Qz, const void *rec16, double qmax,
+                         size_t m, size_t m_pad, int q_splits, const uint32_t *idx_prev, double *out_key, uint32_t *out_idx)
+{
+    if (n_pad == 0 || m_pad == 0 || n_pad % 2048 || m_pad % kTileQH || q_splits < 1 || m > m_pad || !(qmax > 0.0))
+        return hipErrorInvalidValue;
+    const unsigned m_scan = (unsigned)search_scan_rows(m);
+    const unsigned q_per_split = (unsigned)search_rows_per_split(m, q_splits);
+    const double sigma = search_mfma16_scale(qmax);
+    const double escale = getenv("ICP_AMD_MFMA16_ESCALE") ? atof(getenv("ICP_AMD_MFMA16_ESCALE")) : 1.0;   // EXPERIMENT ONLY
+#define ICPK_CASE(G_) \
+    if (groups == G_) { \
+        dim3 grid((unsigned)(n_pad / (128 * G_)), (unsigned)q_splits); \
+        search_mfma16_kernel<G_><<<grid, kWG, 0, s>>>(P.x, P.y, P.z, pc, Qz.x, Qz.y, Qz.z, (const Half8 *)rec16, qmax, sigma, escale, \
+                                                    (unsigned)n_pad, (unsigned)m, (unsigned)m_pad, m_scan, q_per_split, idx_prev, \
+                                                    out_key, out_idx); \
+        return hipGetLastError(); \
+    }
+    ICPK_CASE(2) ICPK_CASE(4) ICPK_CASE(8)
+#undef ICPK_CASE
+    return hipErrorInvalidValue;
 }
 
 int search_mfma_rows_per_workgroup(int groups) { return 128 * groups; }

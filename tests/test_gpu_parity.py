@@ -90,7 +90,7 @@ def test_f32_prefilter_whole_loop_and_scale_robustness(monkeypatch):
         assert np.array_equal(a, b), (scale, shift)
 
 
-@pytest.mark.parametrize("groups", ["2", "4", "8"])
+@pytest.mark.parametrize("groups", ["2", "4", "8", "16"])
 def test_matrix_pipe_prefilter_is_only_a_filter(monkeypatch, groups):
     """ICP_AMD_MFMA=2|4|8: the same fp32 filter on v_mfma_f32_32x32x2_f32 (search_mfma.hip, opt-in).  Same indices as the
     oracle on the golden cases (whole loop, seeded iterations included), on the adversarial ties (stage level, several
