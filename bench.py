@@ -24,6 +24,8 @@ sys.path.insert(0, ROOT)
 PEAK_FP64_VALU_NOFMA = 39.3e12   # 256 CU x 4 SIMD x 16 fp64 lanes/clk x 2.4 GHz, one flop per op
 PEAK_FP32_VALU = 157.3e12        # MI355X fp32 vector peak (MI355X_MICROARCH.md; packed FMA counted as 2 flops per lane)
 FLOPS_PER_PAIR = 8               # 3 sub, 3 mul, 2 add: the oracle's un-fused distance
+PEAK_F16_MFMA = 2500e12          # MI355X dense f16 / bf16 matrix peak (MI355X_MICROARCH.md: ~2.5 PF dense)
+CUS, CLOCK_HZ = 256, 2.4e9
 
 
 def measured_traffic(kernel, n, m, world):
@@ -34,8 +36,8 @@ def measured_traffic(kernel, n, m, world):
     except (OSError, ValueError):
         return None
     if rec and rec["n"] == n and rec["m"] == m and rec["n_gpus"] == world:
-        return rec["traffic_bytes"]
-    return None
+        return rec["traffic_bytes"], rec.get("source", "")
+    return None, ""
 
 
 def roofline(variant, n_local, M, avg_ms, launches):
@@ -43,6 +45,22 @@ def roofline(variant, n_local, M, avg_ms, launches):
     pairs of one launch / the kernel's hipEvent-timed average launch duration, whatever instruction mix the variant's
     fast path really issues; `peak` is the VALU peak of the arithmetic type that fast path runs in."""
     ach = FLOPS_PER_PAIR * float(n_local) * float(M) / (avg_ms * 1e-3) if avg_ms > 0 else 0.0
+    if variant == "f32" and os.environ.get("ICP_AMD_MFMA", "16") == "16":
+        # the default F32 filter: one v_mfma_f32_32x32x16_f16 per 32 targets x 32 source rows on operands in two fp16 pieces
+        pairs = float(n_local) * float(M)
+        issued = 32.0 * pairs / (avg_ms * 1e-3) if avg_ms > 0 else 0.0        # K = 16: 32 matrix flops issued per pair
+        valu_floor_ms = pairs * 0.5 / (CUS * 4 * 16 * CLOCK_HZ) * 1e3           # half a v_min3_f32 per pair at one lane-op per lane-clock
+        return {"bound": "mfma", "kernel": "search_mfma16_kernel", "achieved": ach / 1e12, "peak": PEAK_F16_MFMA / 1e12,
+                "unit": "TFLOP/s", "frac": ach / PEAK_F16_MFMA, "flops_per_pair": FLOPS_PER_PAIR, "pairs_per_launch": pairs,
+                "avg_launch_ms": avg_ms, "launches": launches, "traffic": None, "variant": variant,
+                "mfma_flops_issued_per_pair": 32, "mfma_issued_tflops": issued / 1e12, "mfma_pipe_frac": issued / PEAK_F16_MFMA,
+                "valu_floor_ms": valu_floor_ms, "frac_of_valu_floor": valu_floor_ms / avg_ms if avg_ms > 0 else 0.0,
+                "instruction_mix": "fast path = fp16 MFMA pre-filter (operands split into hi + lo fp16 pieces, 15 of the 16 K slots "
+                                   "used) + 0.5 v_min3_f32 per pair on the VALU, co-executing; every candidate re-evaluated in "
+                                   "un-fused fp64 (indices bit-identical to the fp64 variants)",
+                "note": "`achieved` counts the ALGORITHMIC 8 flops per pair against the dense f16 MFMA peak (2.5 PFLOP/s); the "
+                        "matrix pipe itself is `mfma_pipe_frac` busy (32 issued flops per pair), and what binds the kernel is "
+                        "VALU issue: `valu_floor_ms` is the time of its half v_min3_f32 per pair alone"}
     f32 = variant == "f32"
     peak = PEAK_FP32_VALU if f32 else PEAK_FP64_VALU_NOFMA
     mix = {"f32": "fast path = fp32 pre-filter, 3 v_fma_f32 (or 1.5 v_pk_fma_f32) + 0.5 v_min3_f32 per pair; every candidate "
@@ -319,10 +337,13 @@ def main():
                                         "synchronize (rank 0's clock); not part of `value`"},
         }
         if geo["variant"] == "f32":
-            out["roofline"]["traffic"] = measured_traffic("search_f32_kernel", N, M, world)
-            out["roofline"]["traffic_note"] = ("bytes per launch at the L2's memory side (FETCH_SIZE x 2 + WRITE_SIZE, separate "
-                                               "rocprofv3 --pmc passes, profiles/r1_v8_pmc_*.txt); includes Infinity-Cache hits; "
-                                               "the kernel is VALU bound: this is 0.14 TB/s")
+            tb, src = measured_traffic(out["roofline"]["kernel"], N, M, world)
+            out["roofline"]["traffic"] = tb
+            if tb:
+                out["roofline"]["traffic_note"] = (
+                    "bytes per launch at the L2's memory side (FETCH_SIZE x 2 + WRITE_SIZE, separate rocprofv3 --pmc passes: %s); "
+                    "includes Infinity-Cache hits; the kernel is not memory bound: this is %.2f TB/s"
+                    % (src, tb / (search_avg_ms * 1e-3) / 1e12))
         if grid:
             out["grid_search"] = grid
         if world == 1 and not args.no_fp64_variants:

@@ -329,20 +329,21 @@ static int requested_variant(const icp_amd_engine *e)
     if (sv && !strcmp(sv, "auto")) variant = 0;
     return variant;
 }
-// ICP_AMD_MFMA=2|4|8 runs F32's pre-filter on the matrix pipe (search_mfma.hip; the value is the number of 32-row source
-// groups per wave).  Off by default: on gfx950 the fp32 MFMA does not co-execute with VALU instructions
-// (SQ_VALU_MFMA_COEXEC_CYCLES = 0), so the min/event work is added to the 64 cycles per MFMA instead of hiding behind
-// them -- 1M x 1M: 74.2 ms against 67.3 ms for the packed-VALU kernel (profiles/r1_v8_mfma_experiment.txt).
-static int mfma_groups()
+// F32's pre-filter runs on the matrix pipe: by default on the fp16 K = 16 MFMA with every operand in two fp16 pieces
+// (search_mfma.hip; 2.3 times the packed-VALU kernel at 1M x 1M, same results).  ICP_AMD_MFMA=0 selects the packed-VALU
+// kernel, ICP_AMD_MFMA=2|4|8 the fp32 MFMA (measured slower than either: it does not co-execute with the VALU; the value
+// is its number of 32-row source groups per wave), ICP_AMD_MFMA_G the groups of the fp16 kernel.
+static int mfma_groups(size_t n_pad)
 {
-    const int v = env_int("ICP_AMD_MFMA", 0);
-    if (v == 16) {   // the fp16 K = 16 instruction; groups from ICP_AMD_MFMA_G
-        const int g = env_int("ICP_AMD_MFMA_G", 4);
+    const int v = env_int("ICP_AMD_MFMA", 16);
+    if (v == 16) {
+        // 128 source rows x groups per workgroup: small clouds need the workgroups more than the operand reuse
+        const int g = env_int("ICP_AMD_MFMA_G", n_pad < 120000 ? 2 : 4);
         return (g == 2 || g == 4 || g == 8) ? g : 4;
     }
     return (v == 2 || v == 4 || v == 8) ? v : 0;
 }
-static bool mfma_fp16() { return env_int("ICP_AMD_MFMA", 0) == 16; }
+static bool mfma_fp16() { return env_int("ICP_AMD_MFMA", 16) == 16; }
 
 // AUTO searches on the grid from this many targets on: the grid saves 18 us per iteration at 1000 targets (36 at 2000)
 // and costs about 250 us more to set up (tools/tiny_probe.py), so it pays from roughly 15 iterations on here.
@@ -384,7 +385,7 @@ static void choose_geometry(icp_amd_engine *e)
     size_t want = (size_t)(sqrt(pairs) / 40.0 * ((double)cus / 256.0));
     if (want < 2 * cus) want = 2 * cus;
     if (want > 64 * cus) want = 64 * cus;
-    e->mfma_g = f32 ? mfma_groups() : 0;
+    e->mfma_g = f32 ? mfma_groups(e->n_pad) : 0;
     e->mfma16 = e->mfma_g && mfma_fp16();
     const size_t xblocks = e->n_pad / (e->mfma_g ? (size_t)search_mfma_rows_per_workgroup(e->mfma_g) : (size_t)kWG * ppl);
     size_t splits = (want + xblocks - 1) / xblocks;
@@ -1289,11 +1290,11 @@ extern "C" int icp_amd_correspondences(const double *P, size_t n, const double P
                 DevBuf rec16;
                 HIPCHK(rec16.alloc(32 * m_pad));
                 HIPCHK(build_qrec16(s, dQ, m, m_pad, sqrt(qmax2), rec16.p));
-                HIPCHK(search_mfma16(s, mfma_groups(), dP, n_pad, pc.as<double>(), dQ, rec16.p, sqrt(qmax2), m, m_pad, q_splits, nullptr,
+                HIPCHK(search_mfma16(s, mfma_groups(n_pad), dP, n_pad, pc.as<double>(), dQ, rec16.p, sqrt(qmax2), m, m_pad, q_splits, nullptr,
                                      keys.as<double>(), idxs.as<uint32_t>()));
                 HIPCHK(hipStreamSynchronize(s));   // rec16 is released on scope exit
-            } else if (mfma_groups())
-                HIPCHK(search_mfma(s, mfma_groups(), dP, n_pad, pc.as<double>(), dQ, qrec.p, sqrt(qmax2), m, m_pad, q_splits, nullptr,
+            } else if (mfma_groups(n_pad))
+                HIPCHK(search_mfma(s, mfma_groups(n_pad), dP, n_pad, pc.as<double>(), dQ, qrec.p, sqrt(qmax2), m, m_pad, q_splits, nullptr,
                                    keys.as<double>(), idxs.as<uint32_t>()));
             else
                 HIPCHK(search_f32(s, ppl, cb, dP, n_pad, pc.as<double>(), dQ, qrec.p, sqrt(qmax2), m, m_pad, q_splits, nullptr,
@@ -1408,6 +1409,38 @@ extern "C" int icp_amd_apply(const double *P, size_t n, const double R[9], const
     HIPCHK(soa_to_aos(s, dP, n, pstage.as<double>()));
     HIPCHK(hipMemcpyAsync(P_out, pstage.p, n * 3 * sizeof(double), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
+    return ICP_AMD_OK;
+}
+
+// test hook (not in the public header): the fp16 MFMA filter's values against exact ones, as a fraction of its error bound.
+// P (n rows, centred) against Qz (m rows, m a multiple of 32, every 32 consecutive rows identical); n is padded to 32.
+extern "C" int icp_amd_test_mfma16_bound(const double *P, size_t n, const double *Qz, size_t m, double *worst_ratio)
+{
+    if (!P || !Qz || !worst_ratio || n == 0 || m == 0 || m % 32) return fail(ICP_AMD_EINVAL, "icp_amd_test_mfma16_bound: bad argument");
+    RCCHK(require_device(env_int("ICP_AMD_DEVICE", 0)));
+    hipStream_t s = nullptr;
+    const size_t n_pad = round_up(n, kPadRows), m_pad = round_up(m, kPadRows);
+    DevBuf pst, pstage, qst, qstage, qrec, qmaxb, rec16, worst;
+    Soa3 dP, dQ;
+    RCCHK(upload_soa(s, P, n, n_pad, 0.0, pst, pstage, dP));
+    RCCHK(upload_soa(s, Qz, m, m_pad, std::numeric_limits<double>::infinity(), qst, qstage, dQ));
+    HIPCHK(qrec.alloc(16 * m_pad));
+    HIPCHK(qmaxb.alloc(sizeof(unsigned long long)));
+    HIPCHK(build_qrec(s, dQ, m, m_pad, qrec.p, qmaxb.as<unsigned long long>()));
+    unsigned long long bits = 0;
+    HIPCHK(hipMemcpyAsync(&bits, qmaxb.p, sizeof bits, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    double qmax2;
+    memcpy(&qmax2, &bits, sizeof qmax2);
+    if (!(qmax2 > 1e-30 && qmax2 < 1e30)) return fail(ICP_AMD_EINVAL, "icp_amd_test_mfma16_bound: target range outside the filter's domain");
+    HIPCHK(rec16.alloc(32 * m_pad));
+    HIPCHK(build_qrec16(s, dQ, m, m_pad, sqrt(qmax2), rec16.p));
+    HIPCHK(worst.alloc(sizeof(unsigned long long)));
+    HIPCHK(hipMemsetAsync(worst.p, 0, sizeof(unsigned long long), s));
+    HIPCHK(mfma16_probe(s, dP, round_up(n, 32), dQ, m, m_pad, sqrt(qmax2), rec16.p, worst.as<unsigned long long>()));
+    HIPCHK(hipMemcpyAsync(&bits, worst.p, sizeof bits, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    memcpy(worst_ratio, &bits, sizeof *worst_ratio);
     return ICP_AMD_OK;
 }
 

@@ -81,6 +81,10 @@ hipError_t build_qrec16(hipStream_t s, Soa3 Qz, size_t m, size_t m_pad, double q
 hipError_t search_mfma16(hipStream_t s, int groups, Soa3 P, size_t n_pad, const double *pc, Soa3 Qz, const void *rec16, double qmax,
                          size_t m, size_t m_pad, int q_splits, const uint32_t *idx_prev, double *out_key, uint32_t *out_idx);
 
+// test hook: max over (source, target) pairs of |filter value - exact| / bound; targets in runs of 32 identical points
+hipError_t mfma16_probe(hipStream_t s, Soa3 P, size_t n32, Soa3 Qz, size_t m32, size_t m_pad, double qmax, const void *rec16,
+                        unsigned long long *worst_bits);
+
 // Uniform grid over the centred target cloud (grid.hip): same correspondences as the brute-force kernels, found by
 // evaluating only the targets in the cells a query's search box touches.
 // one empty launch from grid.hip: loads that translation unit's code object (icp_amd_init)

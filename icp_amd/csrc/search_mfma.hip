@@ -163,15 +163,19 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(2))) void s
 // coordinate at 2^6..2^7, far from fp16's overflow and with the lo pieces mostly above its subnormals:
 //     s' = sigma^2 (|q|^2 - 2 p.q) = sum over c of (Th + Tl)(Ph + Pl) + (W0 + W1 + W2),   T = -2 sigma q_c, P = sigma p_c, W = sigma^2 |q|^2
 // = 15 products (the 16th slot is 0): half 0 of the wave carries x and y, half 1 carries z and the three pieces of W
-// against ones.  Every product of two fp16 values is exact in fp32, so the error is the pieces' truncation
-// (<= 2^-22 relative each, or 2^-14 absolute for a piece in the subnormal range should the pipe flush it) plus the fp32
-// accumulation of 16 terms:
-//     |s'_computed - s'| <= 2^-20 (|P| Tmax + Wmax) + 2^-13 (|P| + Tmax) + 2^-12 =: E'    (all in scaled units),
-// the first term being the standard bound for 16 sequential fp32 additions (4 times what a pipe that rounds once per four
-// products would need).  Everything else is the fp32 filter: threshold sigma^2 (bd (1 + 2^-50) - |p|^2 (1 - 2^-50)) + E', exact
-// re-evaluation of every block that trips it.  A source row whose scaled coordinates leave fp16's range multiplies by
-// zero instead and takes the exact path on every block.
+// against ones.  Every product of two fp16 values is exact in fp32, so the error is
+//  * the pieces' truncation: |v - hi - lo| <= 2^-22 |v| for each operand, i.e. <= 2^-21 |P||T| over the three products;
+//  * the fp32 accumulation of 15 terms: <= 15 * 2^-23 (|P||T| + W) even for a pipe that truncates instead of rounding;
+//  * a lo piece in fp16's subnormal range (below 2^-14), should the pipe flush it: <= 2^-14 times its partner, over all
+//    pieces <= 2^-13 (|P| + Tmax), and 2^-13 for the pieces of W:
+//     |s'_computed - s'| <= 2^-18 (|P| Tmax + Wmax) + 2^-13 (|P| + Tmax) + 2^-12 =: E'    (all in scaled units),
+// with a factor two in hand on the first term.  Everything else is the fp32 filter: threshold
+// sigma^2 (bd (1 + 2^-50) - |p|^2 (1 - 2^-50)) + E', exact re-evaluation of every block of 64 targets that trips it.  A
+// source row whose scaled coordinates leave fp16's range multiplies by zero instead and takes the exact path on every
+// block.  Measured (1M x 1M, one MI355X): 28.7 ms per iteration against 66 ms for the packed-VALU filter; the fp16 MFMA
+// (32 cycles each) co-executes with the VALU, which is left with half a v_min3_f32 per pair.
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+double search_mfma16_scale(double qmax);
 
 struct __attribute__((aligned(16))) Half8 { _Float16 v[8]; };
 
@@ -210,6 +214,12 @@ __global__ __launch_bounds__(kWG) void build_qrec16_kernel(const double *__restr
     rec16[m_pad + i] = b;
 }
 
+// E' of the header comment; pl = sigma |p|, tmax = 2 sigma qmax, wmax = sigma^2 qmax^2
+__device__ __forceinline__ double mfma16_bound(double pl, double tmax, double wmax)
+{
+    return 0x1p-18 * (pl * tmax + wmax) + 0x1p-13 * (pl + tmax) + 0x1p-12;
+}
+
 constexpr int kTileQH = 1024;   // targets per LDS tile (2 x 16 KB)
 constexpr int kRowsH = 64;      // targets between event checks of the fp16 filter = two MFMA blocks (= kSplitGran)
 
@@ -217,7 +227,7 @@ template <int G>
 __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(2))) void search_mfma16_kernel(
     const double *__restrict__ px, const double *__restrict__ py, const double *__restrict__ pz, const double *__restrict__ pc,
     const double *__restrict__ qx, const double *__restrict__ qy, const double *__restrict__ qz, const Half8 *__restrict__ rec16,
-    double qmax, double sigma, double escale, unsigned n_pad, unsigned m, unsigned m_pad, unsigned m_scan, unsigned q_per_split,
+    double qmax, double sigma, unsigned n_pad, unsigned m, unsigned m_pad, unsigned m_scan, unsigned q_per_split,
     const uint32_t *__restrict__ idx_prev, double *__restrict__ out_key, uint32_t *__restrict__ out_idx)
 {
     __shared__ Half8 st[2][kTileQH];
@@ -237,7 +247,7 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(2))) void s
     // threshold in scaled units from the exact running bound
     auto threshold = [&](double bdv, double pn) -> float {
         const double pl = sigma * sqrt(pn);
-        const double E = escale * (0x1p-20 * (pl * tmax + wmax) + 0x1p-13 * (pl + tmax) + 0x1p-12);
+        const double E = mfma16_bound(pl, tmax, wmax);
         const bool usable = pn < 1e30 && pl < 16384.0;
         return f32_above(usable ? s2 * ((bdv - pn) + (bdv + pn) * 0x1p-50) + E : INFINITY);
     };
@@ -336,6 +346,50 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(2))) void s
     }
 }
 
+// Test hook: the filter values of the kernel above against the exact ones.  The targets come in runs of 32 identical
+// points, so that all 16 values a lane gets back for a block belong to one (source, target) pair whatever the row order of
+// the instruction's result layout.  *worst = max over all pairs of |s'_computed - s'_exact| / E'(p): the bound holds on the
+// data iff it is <= 1.  P is taken as already centred; one wave per (32 source rows, one block of 32 targets).
+__global__ __launch_bounds__(64) void mfma16_probe_kernel(const double *__restrict__ px, const double *__restrict__ py,
+                                                          const double *__restrict__ pz, const double *__restrict__ qx,
+                                                          const double *__restrict__ qy, const double *__restrict__ qz,
+                                                          const Half8 *__restrict__ rec16, double qmax, double sigma,
+                                                          unsigned m_pad, unsigned long long *__restrict__ worst_bits)
+{
+    const unsigned lane = threadIdx.x, col = lane & 31u, half = lane >> 5;
+    const unsigned row = blockIdx.x * 32u + col, j0 = blockIdx.y * 32u;
+    const double ax = px[row], ay = py[row], az = pz[row];
+    const double pn = (ax * ax + ay * ay) + az * az, pl = sigma * sqrt(pn);
+    if (!(pl < 16384.0)) return;   // whole-wave decision is not needed: such lanes simply do not report
+    _Float16 xh, xl, yh, yl, zh, zl;
+    split16(sigma * ax, xh, xl);
+    split16(sigma * ay, yh, yl);
+    split16(sigma * az, zh, zl);
+    const _Float16 one = (_Float16)1.0f, zero = (_Float16)0.0f;
+    const f16x8 b0 = {xh, xl, xh, xl, yh, yl, yh, yl};
+    const f16x8 b1 = {zh, zl, zh, zl, one, one, one, zero};
+    const f16x8 a = *(const f16x8 *)&rec16[(size_t)half * m_pad + j0 + col];
+    const f32x16 zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, half ? b1 : b0, zero16, 0, 0, 0);
+    const double tx = qx[j0], ty = qy[j0], tz = qz[j0];   // the block's one target
+    const double exact = sigma * sigma * (((tx * tx + ty * ty) + tz * tz) - 2.0 * ((ax * tx + ay * ty) + az * tz));
+    const double E = mfma16_bound(pl, 2.0 * sigma * qmax, sigma * sigma * qmax * qmax);
+    double worst = 0.0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) worst = fmax(worst, fabs((double)acc[r] - exact) / E);
+    atomicMax(worst_bits, (unsigned long long)__double_as_longlong(worst));   // non-negative doubles order like their bits
+}
+
+hipError_t mfma16_probe(hipStream_t s, Soa3 P, size_t n32, Soa3 Qz, size_t m32, size_t m_pad, double qmax, const void *rec16,
+                        unsigned long long *worst_bits)
+{
+    if (n32 == 0 || m32 == 0 || n32 % 32 || m32 % 32 || !(qmax > 0.0)) return hipErrorInvalidValue;
+    mfma16_probe_kernel<<<dim3((unsigned)(n32 / 32), (unsigned)(m32 / 32)), 64, 0, s>>>(P.x, P.y, P.z, Qz.x, Qz.y, Qz.z, (const Half8 *)rec16,
+                                                                                      qmax, search_mfma16_scale(qmax), (unsigned)m_pad,
+                                                                                      worst_bits);
+    return hipGetLastError();
+}
+
 // sigma: the power of two that puts qmax (the largest |q| of the centred target) into [2^6, 2^7)
 double search_mfma16_scale(double qmax)
 {
@@ -360,11 +414,10 @@ hipError_t search_mfma16(hipStream_t s, int groups, Soa3 P, size_t n_pad, const 
     const unsigned m_scan = (unsigned)search_scan_rows(m);
     const unsigned q_per_split = (unsigned)search_rows_per_split(m, q_splits);
     const double sigma = search_mfma16_scale(qmax);
-    const double escale = getenv("ICP_AMD_MFMA16_ESCALE") ? atof(getenv("ICP_AMD_MFMA16_ESCALE")) : 1.0;   // EXPERIMENT ONLY
 #define ICPK_CASE(G_) \
     if (groups == G_) { \
         dim3 grid((unsigned)(n_pad / (128 * G_)), (unsigned)q_splits); \
-        search_mfma16_kernel<G_><<<grid, kWG, 0, s>>>(P.x, P.y, P.z, pc, Qz.x, Qz.y, Qz.z, (const Half8 *)rec16, qmax, sigma, escale, \
+        search_mfma16_kernel<G_><<<grid, kWG, 0, s>>>(P.x, P.y, P.z, pc, Qz.x, Qz.y, Qz.z, (const Half8 *)rec16, qmax, sigma, \
                                                     (unsigned)n_pad, (unsigned)m, (unsigned)m_pad, m_scan, q_per_split, idx_prev, \
                                                     out_key, out_idx); \
         return hipGetLastError(); \

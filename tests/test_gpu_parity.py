@@ -90,9 +90,42 @@ def test_f32_prefilter_whole_loop_and_scale_robustness(monkeypatch):
         assert np.array_equal(a, b), (scale, shift)
 
 
-@pytest.mark.parametrize("groups", ["2", "4", "8", "16"])
+def test_fp16_matrix_filter_stays_inside_its_error_bound():
+    """The default F32 pre-filter computes sigma^2 (|q|^2 - 2 p.q) on v_mfma_f32_32x32x16_f16 from operands split into two
+    fp16 pieces; the search is exact only if the value is within E' of the true one (search_mfma.hip).  A test kernel
+    compares every filter value with the exact one (targets in runs of 32 identical points, so the instruction's result
+    layout does not matter) and returns the worst |error| / E': at most 1 by the derivation -- in fact a small fraction of
+    it -- over scales, offsets from the centre, coordinates near zero (lo pieces in fp16's subnormal range) and far sources."""
+    import ctypes as C
+    rng = np.random.RandomState(12)
+    worst_seen = 0.0
+    for case in range(14):
+        scale = 10.0 ** rng.uniform(-12, 12) if case % 2 else 1.0
+        T, n = 96, 700
+        q = rng.uniform(-1, 1, (T, 3))
+        p = rng.uniform(-1, 1, (n, 3))
+        if case % 3 == 0:
+            q[:, 2] = 0.0; p[::3, 1] = 0.0                      # exact zeros
+        if case % 3 == 1:
+            q[: T // 2] *= 10.0 ** rng.uniform(-9, -1, (T // 2, 1))   # coordinates tiny against qmax: lo pieces underflow
+            p[: n // 2] *= 10.0 ** rng.uniform(-9, -1, (n // 2, 1))
+        if case % 4 == 3:
+            p[::5] *= rng.uniform(1, 100, (len(p[::5]), 1))      # sources well outside the target's extent (still in fp16 range)
+        Qz = np.ascontiguousarray(np.repeat(q * scale, 32, axis=0))
+        P = np.ascontiguousarray(p * scale)
+        w = C.c_double()
+        icp_amd.check(icp_amd.lib().icp_amd_test_mfma16_bound(P.ctypes.data_as(C.c_void_p), C.c_size_t(len(P)),
+                                                              Qz.ctypes.data_as(C.c_void_p), C.c_size_t(len(Qz)), C.byref(w)))
+        assert 0.0 <= w.value <= 1.0, (case, scale, w.value)
+        worst_seen = max(worst_seen, w.value)
+    assert worst_seen > 0.0          # the probe did compare something
+    assert worst_seen < 0.5, worst_seen
+
+
+@pytest.mark.parametrize("groups", ["0", "2", "4", "8", "16"])
 def test_matrix_pipe_prefilter_is_only_a_filter(monkeypatch, groups):
-    """ICP_AMD_MFMA=2|4|8: the same fp32 filter on v_mfma_f32_32x32x2_f32 (search_mfma.hip, opt-in).  Same indices as the
+    """Every implementation of the F32 pre-filter: ICP_AMD_MFMA=16 (the default: v_mfma_f32_32x32x16_f16 on operands in two
+    fp16 pieces), 0 (packed fp32 VALU), 2|4|8 (v_mfma_f32_32x32x2_f32 with that many source groups).  Same indices as the
     oracle on the golden cases (whole loop, seeded iterations included), on the adversarial ties (stage level, several
     splits) and across scales / offsets, where its looser error bound only means more slow-path visits."""
     monkeypatch.setenv("ICP_AMD_SEARCH", "f32")
