@@ -339,7 +339,7 @@ static int mfma_groups(size_t n_pad)
     if (v == 16) {
         // 128 source rows x groups per workgroup: small clouds need the workgroups more than the operand reuse
         const int g = env_int("ICP_AMD_MFMA_G", n_pad < 120000 ? 2 : 4);
-        return (g == 2 || g == 4 || g == 8) ? g : 4;
+        return g == 2 ? 2 : 4;   // four waves per SIMD: eight groups would not fit the register file
     }
     return (v == 2 || v == 4 || v == 8) ? v : 0;
 }

@@ -224,7 +224,7 @@ constexpr int kTileQH = 1024;   // targets per LDS tile (2 x 16 KB)
 constexpr int kRowsH = 64;      // targets between event checks of the fp16 filter = two MFMA blocks (= kSplitGran)
 
 template <int G>
-__global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(2))) void search_mfma16_kernel(
+__global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(4))) void search_mfma16_kernel(
     const double *__restrict__ px, const double *__restrict__ py, const double *__restrict__ pz, const double *__restrict__ pc,
     const double *__restrict__ qx, const double *__restrict__ qy, const double *__restrict__ qz, const Half8 *__restrict__ rec16,
     double qmax, double sigma, unsigned n_pad, unsigned m, unsigned m_pad, unsigned m_scan, unsigned q_per_split,
@@ -422,7 +422,7 @@ hipError_t search_mfma16(hipStream_t s, int groups, Soa3 P, size_t n_pad, const 
                                                     out_key, out_idx); \
         return hipGetLastError(); \
     }
-    ICPK_CASE(2) ICPK_CASE(4) ICPK_CASE(8)
+    ICPK_CASE(2) ICPK_CASE(4)
 #undef ICPK_CASE
     return hipErrorInvalidValue;
 }

@@ -27,7 +27,7 @@ def run(n, m, iters, env):
 sizes = [(int(a), int(b), int(c)) for a, b, c in (s.split("x") for s in sys.argv[1:])] or [(1000000, 1000000, 5), (125952, 1000000, 20), (100000, 100000, 50), (20000, 20000, 100)]
 for n, m, it in sizes:
     for label, env in (("valu", {"ICP_AMD_MFMA": "0"}), ("mfma4", {"ICP_AMD_MFMA": "4"}),
-                       ("h16 g2", {"ICP_AMD_MFMA": "16", "ICP_AMD_MFMA_G": "2"}), ("h16 g4", {"ICP_AMD_MFMA": "16", "ICP_AMD_MFMA_G": "4"}),
-                       ("h16 g8", {"ICP_AMD_MFMA": "16", "ICP_AMD_MFMA_G": "8"})):
+                       ("h16 g2", {"ICP_AMD_MFMA": "16", "ICP_AMD_MFMA_G": "2"}), ("h16 g4", {"ICP_AMD_MFMA": "16", "ICP_AMD_MFMA_G": "4"})
+                       ):
         d = run(n, m, it, env)
         print(f"{n:8d} x {m:8d} {label:6s} {d['ms_per_iteration']:9.3f} ms/iteration  geometry {d['geometry']}  idx hash {d['idx_hash']}", flush=True)

@@ -8,7 +8,7 @@ from icp_amd import synth
 n, m = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (1000000, 1000000)
 splits = [int(x) for x in sys.argv[3].split(",")] if len(sys.argv) > 3 else [4, 6, 9, 12, 18, 27, 40]
 P, Q = synth.make_pair(n, m, seed=5)
-for g in (2, 4, 8):
+for g in (2, 4):
     line = []
     for sp in splits:
         os.environ.update(ICP_AMD_MFMA="16", ICP_AMD_MFMA_G=str(g), ICP_AMD_QSPLITS=str(sp))
