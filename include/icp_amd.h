@@ -48,7 +48,9 @@ extern "C" {
                                      F32 itself degrades to FMA when the clouds' range defeats the fp32 bound  */
 #define ICP_AMD_SEARCH_EXACT  1   /* 8 un-fused fp64 ops per pair, the oracle's own sequence                */
 #define ICP_AMD_SEARCH_FMA    2   /* fused fp64 pre-filter + exact re-evaluation of every candidate         */
-#define ICP_AMD_SEARCH_F32    3   /* fp32 pre-filter with a rigorous error bound + the same exact re-evaluation */
+#define ICP_AMD_SEARCH_F32    3   /* reduced-precision pre-filter with a rigorous error bound + the same exact re-evaluation:
+                                     on the fp16 matrix pipe (operands in two fp16 pieces, fp32 accumulation) by default,
+                                     on the packed fp32 VALU with ICP_AMD_MFMA=0                                        */
 #define ICP_AMD_SEARCH_GRID   4   /* uniform grid over the target: evaluates only the targets near each source point,
                                      with a rounding-safe stop rule; same indices, O(N) instead of O(N M) per iteration */
 
