@@ -97,6 +97,28 @@ def fp64_variants(P, Q, device, steps=3):
     return out
 
 
+def parity_check(P, Q, device, rows=200000, iters=3):
+    """In the bench run itself: the default brute-force search (reduced-precision pre-filter on the matrix pipe + exact fp64
+    re-evaluation of every candidate) against the all-fp64 EXACT variant on a sub-sample of the same clouds.  Indices and
+    every fp64 result must be identical, bit for bit."""
+    import icp_amd
+    n, m = min(rows, len(P)), min(rows, len(Q))
+    got = {}
+    for var in ("f32", "exact"):
+        e = icp_amd.Engine(device=device, search=var)
+        e.set_target(Q[:m])
+        e.set_source(P[:n])
+        e.iterate(iters)
+        last = e.get_last()
+        got[var] = (last["idx"].copy(), last["cov"].copy(), last["R"].copy(), last["t"].copy(), e.get_source())
+        e.close()
+    a, b = got["f32"], got["exact"]
+    return {"workload": "first %d x %d points of the same clouds, %d iterations, default search against the all-fp64 EXACT variant"
+                        % (n, m, iters),
+            "indices_identical": bool(np.array_equal(a[0], b[0])),
+            "cov_R_t_P_identical": bool(all(np.array_equal(x, y) for x, y in zip(a[1:], b[1:])))}
+
+
 def cpu_baseline(P, Q, seconds_target=30.0):
     """The CPU oracle (oracle/icp_oracle.c, a port of the reference CPU path) timed on this host's cores on a
     bounded sample of the same workload: the correspondence search of the first `rows` source points against
@@ -348,6 +370,7 @@ def main():
             out["grid_search"] = grid
         if world == 1 and not args.no_fp64_variants:
             out["fp64_variants"] = fp64_variants(P, Q, local_rank)
+            out["parity_check"] = parity_check(P, Q, local_rank)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(P, Q)
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
