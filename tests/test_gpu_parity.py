@@ -483,3 +483,35 @@ def test_cli_on_the_cow_pair_20_iterations(tmp_path):
     assert relerr(np.load(tmp_path / "out.npy"), g["P_out"]) < TOL
     lines = open(tmp_path / "point_cloud_result").read().split("\n")
     assert lines[0] == " dim0: %d dim1: 3 array: " % len(g["P"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("matrix_pipe", ["16", "0"])
+def test_filter_variants_nonfinite_and_outliers(matrix_pipe, monkeypatch):
+    """Non-finite and far-out-of-range rows on either side: the filtered variants (fp16 matrix pipe, packed fp32) give
+    the exact variant's correspondences, which are the oracle's.  A non-finite or huge target drives the filter's scale
+    and bound to their limits (every block then takes the exact path); a non-finite source row has no correspondence."""
+    monkeypatch.setenv("ICP_AMD_MFMA", matrix_pipe)
+    P, Q = synth.make_pair(3000, 4100, seed=79)
+    Pz, Qz = P - orc.mean0(P), Q - orc.mean0(Q)
+    cases = {}
+    Pn = Pz.copy()
+    Pn[5, 0], Pn[17, 1], Pn[99, 2], Pn[640] = np.nan, np.inf, -np.inf, 1e200
+    cases["source"] = (Pn, Qz)
+    for name, vals in (("target_inf", (np.inf, np.nan)), ("target_huge", (1e19, -3e25)), ("target_tiny", (1e-300, 5e-324))):
+        Qn = Qz.copy()
+        Qn[7, 1], Qn[4000, 0] = vals
+        cases[name] = (Pz, Qn)
+    Qs = Qz * 1e-200
+    cases["all_tiny"] = (Pz * 1e-200, Qs)
+    cases["all_huge"] = (Pz * 1e150, Qz * 1e150)
+    for name, (a, b) in cases.items():
+        want = icp_amd.correspondences(a, np.zeros(3), b, search="exact")
+        if name == "source":
+            assert want[5] == -1 and want[17] == -1 and want[99] == -1
+        if np.isfinite(a).all() and np.isfinite(b).all():
+            assert np.array_equal(want, orc.correspondences(a, b)), name
+        for search in ("fma", "f32"):
+            for splits in (1, 3):
+                got = icp_amd.correspondences(a, np.zeros(3), b, search=search, q_splits=splits)
+                assert np.array_equal(got, want), (name, search, splits)
