@@ -223,7 +223,21 @@ __device__ __forceinline__ double mfma16_bound(double pl, double tmax, double wm
 constexpr int kTileQH = 1024;   // targets per LDS tile (2 x 16 KB)
 constexpr int kRowsH = 64;      // targets between event checks of the fp16 filter = two MFMA blocks (= kSplitGran)
 
-template <int G>
+constexpr int kCoopMax = 8;     // rows of a source group flagged in one block up to which the wave handles them one by one
+
+// minimum over the wave, NaN ignored (fmin); every lane gets the result
+__device__ __forceinline__ double wave_min_f64(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = __builtin_fmin(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// COOP selects how the rare exact path is entered.  false (seeded launches, i.e. every iteration after the first): each
+// flagged lane re-scans the block for its own row -- events are so rare that only the filter loop's register budget
+// matters.  true (unseeded launches: the first iteration, the stage-level correspondence call): the running minimum of a
+// row drops ~ln(M/64) times during the scan, so the wave handles flagged rows cooperatively, one lane per target.
+template <int G, bool COOP>
 __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(4))) void search_mfma16_kernel(
     const double *__restrict__ px, const double *__restrict__ py, const double *__restrict__ pz, const double *__restrict__ pc,
     const double *__restrict__ qx, const double *__restrict__ qy, const double *__restrict__ qz, const Half8 *__restrict__ rec16,
@@ -313,18 +327,83 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(4))) void s
                 if (blk == sblk[g]) ms[g] = thr[g];   // the seed's own block was evaluated exactly by seed_init
                 ev |= (ms[g] < thr[g]);
             }
-            if (ev) {
+            if constexpr (COOP) {
+                if (__ballot(ev)) {   // wave-uniform: the cooperative path below needs every lane
+                    const unsigned jg = t0 + (unsigned)j0;
+                    const double tqx = qx[jg + lane], tqy = qy[jg + lane], tqz = qz[jg + lane];   // lane u <-> target jg + u
 #pragma unroll
-                for (int g = 0; g < G; ++g) {
-                    if (ms[g] < thr[g]) {
+                    for (int g = 0; g < G; ++g) {
+                        const bool mine = ms[g] < thr[g];
+                        unsigned long long mk = __ballot(mine);
+                        if (mk == 0) continue;
                         const unsigned row = base + g * 32u;
-                        const double ax = px[row] - c0, ay = py[row] - c1, az = pz[row] - c2;
-                        const double pn = (ax * ax + ay * ay) + az * az;
-                        const unsigned jg = t0 + (unsigned)j0;
-                        double dbest;
-                        rescan_block<kRowsH>(ax, ay, az, qx + jg, qy + jg, qz + jg, 0, jg, bd[g], bk[g], bj[g], dbest);
-                        thr[g] = threshold(bd[g], pn);
-                        ms[g] = thr[g];
+                        if (__popcll(mk) > kCoopMax) {
+                            // many rows at once (the first blocks of the scan): each lane re-scans for its own row
+                            if (mine) {
+                                const double ax = px[row] - c0, ay = py[row] - c1, az = pz[row] - c2;
+                                const double pn = (ax * ax + ay * ay) + az * az;
+                                double dbest;
+                                rescan_block<kRowsH>(ax, ay, az, qx + jg, qy + jg, qz + jg, 0, jg, bd[g], bk[g], bj[g], dbest);
+                                thr[g] = threshold(bd[g], pn);
+                                ms[g] = thr[g];
+                            }
+                            continue;
+                        }
+                        // few rows: the wave takes them one at a time, lane u evaluating target u of the block.  With a
+                        // unique minimum outside the tie band of the second smallest value the outcome of the in-order
+                        // scan is known without running it (rescan_block's own shortcut, evaluated across the wave);
+                        // anything else -- ties, NaN -- is left to that scan.
+                        while (mk) {
+                            const int L = __builtin_ctzll(mk);
+                            mk &= mk - 1;
+                            const unsigned rowL = row - col + ((unsigned)L & 31u);
+                            const double ax = px[rowL] - c0, ay = py[rowL] - c1, az = pz[rowL] - c2;
+                            const double pn = (ax * ax + ay * ay) + az * az;
+                            const double d = d2_exact(ax, ay, az, tqx, tqy, tqz);
+                            const double dm = wave_min_f64(d);
+                            const unsigned long long eq = __ballot(d == dm);
+                            const unsigned long long bad = __ballot(d != d);
+                            const double bdL = __shfl(bd[g], L, 64);
+                            if (!bad && !(dm < bdL)) {   // false alarm of the filter
+                                if ((int)lane == L) ms[g] = thr[g];
+                                continue;
+                            }
+                            const int um = eq ? __builtin_ctzll(eq) : 0;
+                            const double d2nd = (__popcll(eq) == 1) ? wave_min_f64((int)lane == um ? INFINITY : d) : dm;
+                            const bool direct = !bad && d2nd > tie_band(dm);
+                            if ((int)lane == L) {
+                                if (direct) {
+                                    bd[g] = dm;
+                                    const double key = key_of(dm);
+                                    const uint32_t j = jg + (unsigned)um;
+                                    if (key < bk[g] || (key == bk[g] && j < bj[g])) {
+                                        bk[g] = key;
+                                        bj[g] = j;
+                                    }
+                                } else {
+                                    double dbest;
+                                    rescan_block<kRowsH>(ax, ay, az, qx + jg, qy + jg, qz + jg, 0, jg, bd[g], bk[g], bj[g], dbest);
+                                }
+                                thr[g] = threshold(bd[g], pn);
+                                ms[g] = thr[g];
+                            }
+                        }
+                    }
+                }
+            } else {
+                if (ev) {
+#pragma unroll
+                    for (int g = 0; g < G; ++g) {
+                        if (ms[g] < thr[g]) {
+                            const unsigned row = base + g * 32u;
+                            const double ax = px[row] - c0, ay = py[row] - c1, az = pz[row] - c2;
+                            const double pn = (ax * ax + ay * ay) + az * az;
+                            const unsigned jg = t0 + (unsigned)j0;
+                            double dbest;
+                            rescan_block<kRowsH>(ax, ay, az, qx + jg, qy + jg, qz + jg, 0, jg, bd[g], bk[g], bj[g], dbest);
+                            thr[g] = threshold(bd[g], pn);
+                            ms[g] = thr[g];
+                        }
                     }
                 }
             }
@@ -417,9 +496,14 @@ hipError_t search_mfma16(hipStream_t s, int groups, Soa3 P, size_t n_pad, const 
 #define ICPK_CASE(G_) \
     if (groups == G_) { \
         dim3 grid((unsigned)(n_pad / (128 * G_)), (unsigned)q_splits); \
-        search_mfma16_kernel<G_><<<grid, kWG, 0, s>>>(P.x, P.y, P.z, pc, Qz.x, Qz.y, Qz.z, (const Half8 *)rec16, qmax, sigma, \
-                                                    (unsigned)n_pad, (unsigned)m, (unsigned)m_pad, m_scan, q_per_split, idx_prev, \
-                                                    out_key, out_idx); \
+        if (idx_prev) \
+            search_mfma16_kernel<G_, false><<<grid, kWG, 0, s>>>(P.x, P.y, P.z, pc, Qz.x, Qz.y, Qz.z, (const Half8 *)rec16, qmax, \
+                                                               sigma, (unsigned)n_pad, (unsigned)m, (unsigned)m_pad, m_scan, \
+                                                               q_per_split, idx_prev, out_key, out_idx); \
+        else   /* unseeded: many exact-path entries, handled by the wave cooperatively */ \
+            search_mfma16_kernel<G_, true><<<grid, kWG, 0, s>>>(P.x, P.y, P.z, pc, Qz.x, Qz.y, Qz.z, (const Half8 *)rec16, qmax, \
+                                                              sigma, (unsigned)n_pad, (unsigned)m, (unsigned)m_pad, m_scan, \
+                                                              q_per_split, idx_prev, out_key, out_idx); \
         return hipGetLastError(); \
     }
     ICPK_CASE(2) ICPK_CASE(4)
