@@ -223,7 +223,10 @@ __device__ __forceinline__ double mfma16_bound(double pl, double tmax, double wm
 constexpr int kTileQH = 1024;   // targets per LDS tile (2 x 16 KB)
 constexpr int kRowsH = 64;      // targets between event checks of the fp16 filter = two MFMA blocks (= kSplitGran)
 
-constexpr int kCoopMax = 8;     // rows of a source group flagged in one block up to which the wave handles them one by one
+#ifndef ICPK_COOPMAX
+#define ICPK_COOPMAX 8
+#endif
+constexpr int kCoopMax = ICPK_COOPMAX;     // rows of a source group flagged in one block up to which the wave handles them one by one
 
 // minimum over the wave, NaN ignored (fmin); every lane gets the result
 __device__ __forceinline__ double wave_min_f64(double v)
@@ -493,6 +496,7 @@ hipError_t search_mfma16(hipStream_t s, int groups, Soa3 P, size_t n_pad, const 
     const unsigned m_scan = (unsigned)search_scan_rows(m);
     const unsigned q_per_split = (unsigned)search_rows_per_split(m, q_splits);
     const double sigma = search_mfma16_scale(qmax);
+    if (!idx_prev) groups = 2;   // the cooperative exact path fits beside two accumulator groups without spilling, not beside four
 #define ICPK_CASE(G_) \
     if (groups == G_) { \
         dim3 grid((unsigned)(n_pad / (128 * G_)), (unsigned)q_splits); \
