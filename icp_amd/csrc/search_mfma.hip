@@ -363,17 +363,28 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(4))) void s
                             const double ax = px[rowL] - c0, ay = py[rowL] - c1, az = pz[rowL] - c2;
                             const double pn = (ax * ax + ay * ay) + az * az;
                             const double d = d2_exact(ax, ay, az, tqx, tqy, tqz);
-                            const double dm = wave_min_f64(d);
-                            const unsigned long long eq = __ballot(d == dm);
                             const unsigned long long bad = __ballot(d != d);
                             const double bdL = __shfl(bd[g], L, 64);
-                            if (!bad && !(dm < bdL)) {   // false alarm of the filter
+                            const unsigned long long lt = __ballot(d < bdL);   // targets of the block that beat the row's bound
+                            if (!bad && lt == 0) {   // false alarm of the filter
                                 if ((int)lane == L) ms[g] = thr[g];
                                 continue;
                             }
-                            const int um = eq ? __builtin_ctzll(eq) : 0;
-                            const double d2nd = (__popcll(eq) == 1) ? wave_min_f64((int)lane == um ? INFINITY : d) : dm;
-                            const bool direct = !bad && d2nd > tie_band(dm);
+                            double dm;
+                            int um;
+                            bool direct;
+                            if (!bad && (lt & (lt - 1)) == 0) {
+                                // exactly one: it is the block's minimum, and unique; no wave reduction needed
+                                um = __builtin_ctzll(lt);
+                                dm = __shfl(d, um, 64);
+                                direct = __popcll(__ballot(d <= tie_band(dm))) == 1;   // nothing else inside its tie band
+                            } else {
+                                dm = wave_min_f64(d);
+                                const unsigned long long eq = __ballot(d == dm);
+                                um = eq ? __builtin_ctzll(eq) : 0;
+                                const double d2nd = (__popcll(eq) == 1) ? wave_min_f64((int)lane == um ? INFINITY : d) : dm;
+                                direct = !bad && d2nd > tie_band(dm);
+                            }
                             if ((int)lane == L) {
                                 if (direct) {
                                     bd[g] = dm;
