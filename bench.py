@@ -28,16 +28,32 @@ PEAK_F16_MFMA = 2500e12          # MI355X dense f16 / bf16 matrix peak (MI355X_M
 CUS, CLOCK_HZ = 256, 2.4e9
 
 
+def blob_hash(path):
+    """What `git hash-object` gives the file (no git needed on the GPU box)."""
+    import hashlib
+    data = open(path, "rb").read()
+    return hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest()
+
+
 def measured_traffic(kernel, n, m, world):
-    """Bytes per launch from the committed PMC passes (icp_amd/measured_traffic.json), or None when they were taken on
-    another workload: bench.py cannot collect counters itself (rocprofv3 runs them as separate passes)."""
+    """(bytes per launch, where from, blob hash of the kernel source they were measured on) from the committed PMC passes
+    (icp_amd/measured_traffic.json; written by tools/update_traffic.py), or (None, why, None): bench.py cannot collect
+    counters itself (rocprofv3 runs them as separate passes), so the figure is only reported when it was taken on this
+    workload AND on the kernel source this tree holds."""
     try:
         rec = json.load(open(os.path.join(ROOT, "icp_amd", "measured_traffic.json"))).get(kernel)
     except (OSError, ValueError):
-        return None
-    if rec and rec["n"] == n and rec["m"] == m and rec["n_gpus"] == world:
-        return rec["traffic_bytes"], rec.get("source", "")
-    return None, ""
+        return None, "no measured_traffic.json", None
+    if not rec or (rec["n"], rec["m"], rec["n_gpus"]) != (n, m, world):
+        return None, "no PMC pass on this workload", None
+    src = rec.get("kernel_source")
+    try:
+        now = blob_hash(os.path.join(ROOT, src)) if src else None
+    except OSError:
+        now = None
+    if not now or now != rec.get("kernel_source_blob"):
+        return None, "PMC pass predates the current %s (blob %s, measured on %s)" % (src, now, rec.get("kernel_source_blob")), None
+    return rec["traffic_bytes"], rec.get("source", ""), now
 
 
 def roofline(variant, n_local, M, avg_ms, launches):
@@ -232,6 +248,35 @@ def bench_batch(args, rank, world, local_rank):
         td.destroy_process_group()
 
 
+def launch_ranks(n):
+    """Runs this same command line under torch.distributed.run with `n` ranks on 127.0.0.1 and relays rank 0's JSON line."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = []
+    for ln in proc.stdout:
+        if ln.startswith("{"):
+            lines.append(ln)
+        else:
+            sys.stderr.write(ln)
+    rc = proc.wait()
+    if lines:
+        sys.stdout.write(lines[-1])
+        sys.stdout.flush()
+    if rc != 0:
+        raise SystemExit(rc)
+    if not lines:
+        raise SystemExit("bench.py: the %d-rank child printed no JSON line" % n)
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -249,7 +294,15 @@ def main():
     ap.add_argument("--batch", type=int, default=4096)
     ap.add_argument("--batch-n", type=int, default=1000)
     ap.add_argument("--batch-iters", type=int, default=20)
+    ap.add_argument("--n1-value", type=float, default=None,
+                    help="`value` of the N=1 run of the same workload: adds scaling_vs_n1 = value / (n_gpus x that) to the line")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` (the shape of the driver's N=1 command): start one rank per GPU as a CHILD process,
+        # before this process has imported torch or touched the GPU (a process that has initialised HIP is never re-exec'd),
+        # relay its output and exit with its code.
+        return launch_ranks(args.gpus)
 
     import torch
     import icp_amd
@@ -289,13 +342,32 @@ def main():
             td.barrier()
         torch.cuda.synchronize()
 
-    def run(search, steps, warmup, repeats=0):
-        """`steps` timed iterations after `warmup` untimed ones: (seconds [max over ranks], search-kernel avg ms,
-        launches, geometry, last iteration's outputs, local rows)."""
+    def all_ranks(x):
+        """[x of rank 0, x of rank 1, ...] as floats (the value itself at world == 1)."""
+        if world == 1:
+            return [float(x)]
+        buf = torch.zeros(world, dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        buf[rank] = float(x)
+        td.all_reduce(buf, op=td.ReduceOp.SUM)
+        return [float(v) for v in buf.cpu()]
+
+    def run(search, steps, warmup, repeats=0, extras=False):
+        """`steps` timed iterations after `warmup` untimed ones.  Returns a dict: seconds (max over ranks), the search
+        kernel's average launch ms (this rank's and every rank's), geometry, the last iteration's outputs, ..."""
         runner = icpdist.ShardedIcp(P, Q, rank=rank, world=world, device=local_rank, search=search, kernel_timing=True)
         runner.begin()
-        for _ in range(warmup):
-            runner.step()
+        first_ms = None
+        for w in range(warmup):
+            if w == 0:
+                # the first iteration of a run has no previous correspondences to seed the search with: timed on its own,
+                # outside the timed region, and reported as `first_step_ms`
+                barrier()
+                t1 = time.perf_counter()
+                runner.step()
+                barrier()
+                first_ms = max(all_ranks((time.perf_counter() - t1) * 1e3))
+            else:
+                runner.step()
         barrier()
         runner.engine.kernel_ms()             # drop the warm-up launches from the kernel timer
         t0 = time.perf_counter()
@@ -303,13 +375,11 @@ def main():
             runner.step()
         barrier()
         dt = time.perf_counter() - t0
-        if world > 1:
-            tmax = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-            td.all_reduce(tmax, op=td.ReduceOp.MAX)
-            dt = float(tmax.item())
+        dt = max(all_ranks(dt))
         avg_ms, _, launches = runner.engine.kernel_ms()
-        res = (dt, avg_ms, launches, runner.engine.search_geometry(), runner.engine.get_last(), runner.n_local,
-               runner.engine.grid_stats())
+        res = {"dt": dt, "avg_ms": avg_ms, "launches": launches, "geo": runner.engine.search_geometry(),
+               "last": runner.engine.get_last(), "n_local": runner.n_local, "grid_stats": runner.engine.grid_stats(),
+               "first_ms": first_ms, "rank_ms": all_ranks(avg_ms)}
         # outside the timed region: a few more steps, each bracketed on its own, for the spread (median + min)
         for _ in range(repeats):
             barrier()
@@ -317,6 +387,30 @@ def main():
             runner.step()
             barrier()
             step_samples.append((time.perf_counter() - t1) * 1e3)
+        if extras and world > 1:
+            # the two exchanges of an iteration on their own (what the ranks wait for besides their kernels): `reps`
+            # all-gathers of each buffer back to back on the runner's stream, bracketed like a step
+            reps = 50
+            res["collective_ms"] = {}
+            for name, buf, width in (("cov_partials", runner.cov, icpdist.COV_W), ("centroid_partials", runner.cen, icpdist.CEN_W)):
+                keep = buf.clone()
+                barrier()
+                t1 = time.perf_counter()
+                with runner._on_stream():
+                    for _ in range(reps):
+                        icpdist.exchange_partials(buf, width, rank, world)
+                barrier()
+                res["collective_ms"][name] = {"ms": max(all_ranks((time.perf_counter() - t1) * 1e3 / reps)), "bytes": buf.numel() * 8}
+                buf.copy_(keep)
+            # SURVEY.md 8e's debug cross-check: every rank solved R, t redundantly from the same gathered partials, so rank 0's
+            # R || t, broadcast, must equal every rank's own bit for bit (always on for N > 1; ICP_AMD_BENCH_CROSSCHECK=0 skips)
+            if os.environ.get("ICP_AMD_BENCH_CROSSCHECK", "1") != "0":
+                mine = torch.from_numpy(np.concatenate([res["last"]["R"].ravel(), res["last"]["t"].ravel()]).copy())
+                root = mine.clone().to("cuda" if backend == "nccl" else "cpu")
+                td.broadcast(root, src=0)
+                same = float(torch.equal(root.cpu(), mine))
+                res["rt_crosscheck"] = {"ranks_identical_to_rank0": int(sum(all_ranks(same))), "of": world,
+                                        "what": "R || t of the last iteration, broadcast from rank 0 and compared bit for bit"}
         runner.close()
         return res
 
@@ -324,16 +418,18 @@ def main():
 
     # Headline: the brute-force search (every one of the N x M distances is evaluated each iteration) -- the path the
     # metric "distance evals/s" and the VALU roofline are defined on.
-    dt, search_avg_ms, launches, geo, last, n_local, _ = run(args.search, args.steps, args.warmup, repeats=5)
+    head = run(args.search, args.steps, args.warmup, repeats=5, extras=True)
+    dt, search_avg_ms, launches, geo, last, n_local = (head[k] for k in ("dt", "avg_ms", "launches", "geo", "last", "n_local"))
     grid = None
     if not args.no_grid and args.search != "grid":
         # The same iterations with the grid search (identical results, a fraction of the distance evaluations):
         # reported beside the headline as iterations/s, never as evals/s.
         g_steps = max(args.steps * 10, 50)
-        g_dt, g_ms, _, g_geo, g_last, _, g_stats = run("grid", g_steps, max(args.warmup, 3))
+        gr = run("grid", g_steps, max(args.warmup, 3))
+        g_dt, g_ms, g_geo, g_stats = gr["dt"], gr["avg_ms"], gr["geo"], gr["grid_stats"]
         grid = {"ms_per_step": g_dt / g_steps * 1e3, "iters_per_sec": g_steps / g_dt, "steps": g_steps,
                 "speedup_vs_brute_force": (dt / args.steps) / (g_dt / g_steps), "search_kernel_avg_ms": g_ms,
-                "search": g_geo, "stats": g_stats,
+                "search": g_geo, "stats": g_stats, "first_step_ms": gr["first_ms"],
                 "note": "exact nearest neighbour over a uniform grid (icp_amd/csrc/grid.hip): same correspondences as the "
                         "brute-force search, only the targets near each source point are evaluated; not counted in `value`"}
 
@@ -353,23 +449,44 @@ def main():
             # dominant kernel (the correspondence search, > 99 % of the step), from its own hipEvent-timed launches
             "roofline": roofline(geo["variant"], n_local, M, search_avg_ms, launches),
             "rms_last": last["rms"],
+            "first_step_ms": head["first_ms"],
+            "search_ms_per_rank": {"max": max(head["rank_ms"]), "min": min(head["rank_ms"]),
+                                   "values": [round(v, 4) for v in head["rank_ms"]]},
+            "process_group": {"ranks": td.get_world_size() if world > 1 else 1,
+                              "backend": (("rccl (torch 'nccl')" if backend == "nccl" else backend) if world > 1 else "none")},
+            "rccl_ranks": (td.get_world_size() if (world > 1 and backend == "nccl") else (1 if world == 1 else 0)),
             "step_ms_samples": {"values": [round(v, 4) for v in step_samples], "median": float(np.median(step_samples)),
                                 "min": float(min(step_samples)),
                                 "note": "five more iterations after the timed region, each bracketed by its own barrier + "
                                         "synchronize (rank 0's clock); not part of `value`"},
         }
         if geo["variant"] == "f32":
-            tb, src = measured_traffic(out["roofline"]["kernel"], N, M, world)
+            tb, src, blob = measured_traffic(out["roofline"]["kernel"], N, M, world)
             out["roofline"]["traffic"] = tb
+            out["roofline"]["traffic_source_commit"] = blob
+            if not tb:
+                out["roofline"]["traffic_note"] = src
             if tb:
                 out["roofline"]["traffic_note"] = (
                     "bytes per launch at the L2's memory side (FETCH_SIZE x 2 + WRITE_SIZE, separate rocprofv3 --pmc passes: %s); "
                     "includes Infinity-Cache hits; the kernel is not memory bound: this is %.2f TB/s"
                     % (src, tb / (search_avg_ms * 1e-3) / 1e12))
+        out["roofline"]["first_step_ms"] = head["first_ms"]
+        if "collective_ms" in head:
+            out["collective_ms"] = head["collective_ms"]
+        if "rt_crosscheck" in head:
+            out["rt_crosscheck"] = head["rt_crosscheck"]
+        if args.n1_value:
+            out["scaling_vs_n1"] = out["value"] / (world * args.n1_value)
+            out["speedup_vs_n1"] = out["value"] / args.n1_value
         if grid:
             out["grid_search"] = grid
         if world == 1 and not args.no_fp64_variants:
             out["fp64_variants"] = fp64_variants(P, Q, local_rank)
+            # the roofline SURVEY.md 8(d) defines: 8 un-fused fp64 flops per pair against the un-fused fp64 VALU peak, for the
+            # two variants whose fast path IS fp64 VALU work (same indices as the headline kernel, same run)
+            for var in ("exact", "fma"):
+                out["roofline"]["frac_fp64_valu_" + var] = out["fp64_variants"][var]["roofline"]["frac"]
             out["parity_check"] = parity_check(P, Q, local_rank)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(P, Q)

@@ -313,7 +313,7 @@ extern "C" int icp_amd_set_target(icp_amd_engine *e, const double *Q, size_t m)
 }
 
 // GRID evaluates only the targets near each source point (grid.hip); the others are brute force over all pairs.
-// Returns 0 for AUTO.
+// Returns 0 for AUTO.  An explicit opt.search wins; the environment variable ICP_AMD_SEARCH only decides what AUTO means.
 static int requested_variant(const icp_amd_engine *e)
 {
     int variant = e->opt.search == ICP_AMD_SEARCH_EXACT  ? kExact
@@ -321,6 +321,7 @@ static int requested_variant(const icp_amd_engine *e)
                   : e->opt.search == ICP_AMD_SEARCH_F32  ? kF32
                   : e->opt.search == ICP_AMD_SEARCH_GRID ? kGrid
                                                          : 0;
+    if (variant != 0) return variant;
     const char *sv = getenv("ICP_AMD_SEARCH");
     if (sv && !strcmp(sv, "fma")) variant = kFma;
     if (sv && !strcmp(sv, "exact")) variant = kExact;
@@ -1114,7 +1115,7 @@ extern "C" int icp_amd_batch_run(icp_amd_batch *b, unsigned iters, int search_va
     HIPCHK(hipSetDevice(b->device));
     // EXACT / FMA: the difference form on SoA targets; anything else (AUTO, F32, GRID): the expanded form on records
     int variant = search_variant == ICP_AMD_SEARCH_EXACT ? kExact : search_variant == ICP_AMD_SEARCH_FMA ? kFma : kExpanded;
-    const char *sv = getenv("ICP_AMD_SEARCH");
+    const char *sv = search_variant == ICP_AMD_SEARCH_AUTO ? getenv("ICP_AMD_SEARCH") : nullptr;   // an explicit variant wins
     if (sv && !strcmp(sv, "fma")) variant = kFma;
     if (sv && !strcmp(sv, "exact")) variant = kExact;
     hipEvent_t a = nullptr, z = nullptr;

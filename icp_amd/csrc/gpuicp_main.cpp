@@ -31,13 +31,8 @@ static std::vector<double> load(const char *path, size_t &rows, size_t &cols)
     return v;
 }
 
-int main(int argc, char **argv)
+static int run(int argc, char **argv, std::future<int> &warm)
 {
-    runtime_assert(argc == 5 || (argc == 6 && std::string(argv[4]) == "-batch"),
-                   "Usage: ./GPUICP file1 file2 nbiters method={-loop|-batch|-shared|-shared-loop}");
-    // the HIP context and the code objects (0.15 s in a fresh process) come up while the input files are parsed; a failure
-    // here is reported by the run below
-    std::future<int> warm = std::async(std::launch::async, [] { return icp_amd_init(-1); });
     size_t Pl, Pc, Ql, Qc;
     // the two files are independent: parse them at the same time (errors surface in file order, like the reference)
     std::future<std::vector<double>> Qf = std::async(std::launch::async, [&] { return load(argv[2], Ql, Qc); });
@@ -83,4 +78,21 @@ int main(int argc, char **argv)
     if (const char *bin = getenv("ICP_AMD_RESULT_FILE"))   // additive: the result in full precision (*.npy / *.f64)
         runtime_assert(icp_amd_write_cloud_binary(bin, P_res.data(), Pl, 3) == ICP_AMD_OK, icp_amd_last_error());
     return 0;
+}
+
+int main(int argc, char **argv)
+{
+    runtime_assert(argc == 5 || (argc == 6 && std::string(argv[4]) == "-batch"),
+                   "Usage: ./GPUICP file1 file2 nbiters method={-loop|-batch|-shared|-shared-loop}");
+    // the HIP context and the code objects (0.15 s in a fresh process) come up while the input files are parsed; a failure
+    // here is reported by the run itself
+    std::future<int> warm = std::async(std::launch::async, [] { return icp_amd_init(-1); });
+    try {
+        return run(argc, argv, warm);
+    } catch (...) {
+        // an argument / shape / parse error ends the process like the reference's uncaught runtime_error -- but never while
+        // the warm-up thread is still inside HIP context creation or a code-object load
+        if (warm.valid()) warm.wait();
+        throw;
+    }
 }

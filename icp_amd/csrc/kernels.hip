@@ -336,13 +336,16 @@ __global__ __launch_bounds__(kWG) void search_f32_kernel(const double *__restric
 #pragma unroll
     for (int s = 0; s < PPL; ++s) {
         const double ax = px[base + s * kWG] - c0, ay = py[base + s * kWG] - c1, az = pz[base + s * kWG] - c2;
-        fx[s] = (float)ax;
-        fy[s] = (float)ay;
-        fz[s] = (float)az;
         const double pn = (ax * ax + ay * ay) + az * az;
         const double E = 0x1p-24 * (11.0 * sqrt(pn) * qmax + 5.0 * qmax * qmax) + 1e-35;
-        // outside the range where the fp32 bound is meaningful the lane simply always takes the exact path
-        off[s] = (pn < 1e30) ? (E - pn) + pn * 0x1p-50 : INFINITY;
+        // outside the range where the fp32 bound is meaningful the lane always takes the exact path: its threshold is +inf
+        // and its filter operands are zero, so that every filter value is the finite |q|^2 (a huge coordinate would
+        // overflow the products to inf / NaN, which v_min3_f32 drops -- the block would be skipped)
+        const bool usable = pn < 1e30;
+        fx[s] = usable ? (float)ax : 0.0f;
+        fy[s] = usable ? (float)ay : 0.0f;
+        fz[s] = usable ? (float)az : 0.0f;
+        off[s] = usable ? (E - pn) + pn * 0x1p-50 : INFINITY;
         const uint32_t js = idx_prev ? idx_prev[base + s * kWG] : 0xFFFFFFFFu;
         bd[s] = seed_init<CB>(ax, ay, az, qx, qy, qz, js, m, q0, q1, bk[s], bj[s], sblk[s]);
         thr[s] = f32_above(__builtin_fma(bd[s], 1.0 + 0x1p-50, off[s]));

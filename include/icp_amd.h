@@ -43,7 +43,9 @@ extern "C" {
 #define ICP_AMD_METHOD_LOOP        2
 #define ICP_AMD_METHOD_BATCH       3
 
-/* Correspondence-search kernel variants (engine option `search`); every variant returns identical indices. */
+/* Correspondence-search kernel variants (engine option `search`); every variant returns identical indices.
+ * An explicit variant is final.  Only AUTO consults the environment: ICP_AMD_SEARCH=exact|fma|f32|grid|auto then decides
+ * what AUTO runs (a debugging aid; icp_amd_search_geometry reports the variant that was planned). */
 #define ICP_AMD_SEARCH_AUTO   0   /* GRID from 1024 targets on (F32 while most search boxes are huge), else F32;
                                      F32 itself degrades to FMA when the clouds' range defeats the fp32 bound  */
 #define ICP_AMD_SEARCH_EXACT  1   /* 8 un-fused fp64 ops per pair, the oracle's own sequence                */

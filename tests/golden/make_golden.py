@@ -76,7 +76,7 @@ def read_trace(path):
     return out
 
 
-def run_icp_case(name, P, Q, iters, keep_p=None, pfile=None, qfile=None):
+def run_icp_case(name, P, Q, iters, keep_p=None, pfile=None, qfile=None, store_inputs=True):
     with tempfile.TemporaryDirectory() as td:
         if pfile is None:
             pfile, qfile = os.path.join(td, "P.csv"), os.path.join(td, "Q.csv")
@@ -91,7 +91,12 @@ def run_icp_case(name, P, Q, iters, keep_p=None, pfile=None, qfile=None):
     tr["P_in_iters"] = np.array(keep, dtype=np.int32)
     # iteration 0 starts from P itself (asserted above): not stored twice; conftest.golden() re-inserts it
     tr["P_in"] = tr["P_in"][[k for k in keep if k > 0]]
-    np.savez_compressed(os.path.join(HERE, name + ".npz"), P=P, Q=Q, iters=np.int32(iters), **tr)
+    if not store_inputs:
+        # the inputs are those of the one-iteration fixture of the same pair (<name without _x20>.npz): not stored twice
+        tr["inputs_from"] = np.array(name.rsplit("_x", 1)[0])
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), iters=np.int32(iters), **tr)
+    else:
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), P=P, Q=Q, iters=np.int32(iters), **tr)
     print("%-14s N=%d M=%d iters=%d  -> %s.npz" % (name, len(P), len(Q), iters, name))
 
 
@@ -192,6 +197,20 @@ def bun045_000():
     run_icp_case("bun045_000", load_csv(pf), load_csv(qf), 1, pfile=pf, qfile=qf)
 
 
+# BASELINE configs[1] at its full length: 20 iterations of the reference loop on the two largest sample pairs
+# (about half an hour of reference CPU time each; the one-iteration fixtures above stay for the quick tests).
+@case
+def horse_tr1_x20():
+    pf, qf = REF + "/icp/horse_tr1.txt", REF + "/icp/horse_ref.txt"
+    run_icp_case("horse_tr1_x20", load_csv(pf), load_csv(qf), 20, keep_p=[0, 1, 10, 19], pfile=pf, qfile=qf, store_inputs=False)
+
+
+@case
+def bun045_000_x20():
+    pf, qf = REF + "/icp/bun045.txt", REF + "/icp/bun000.txt"
+    run_icp_case("bun045_000_x20", load_csv(pf), load_csv(qf), 20, keep_p=[0, 1, 10, 19], pfile=pf, qfile=qf, store_inputs=False)
+
+
 @case
 def syn256():
     P, Q = synth.make_pair(256, 256, seed=101)
@@ -226,6 +245,57 @@ def lattice():
 def ties_corr():
     Pz, Qz = ties_clouds()
     run_corr_case("ties_corr", Pz, Qz)
+
+
+def run_rows_case(name, n, iters_at, n_rows, threads):
+    """Sampled rows of a full-size synthetic pair (the bench's own clouds, synth.make_pair(n, n)) through the REFERENCE's
+    get_correspondence_indices (src/cpu/icp.cpp:72-93) at the iterations `iters_at` (0-based).  The reference cannot walk
+    the whole loop at this size (10 h per iteration at 1M x 1M), so the running cloud P_k comes from the oracle port
+    (oracle/icp_oracle.c, pinned bit-exact to the reference by the other fixtures) and the reference answers for
+    `n_rows` sampled rows against ALL n targets.  Stored: the sampled rows of P_k, Pc_k, the reference's indices, and the
+    previous iteration's indices of those rows (the seeds a seeded search launch starts from).  P and Q themselves are not
+    stored: they are synth.make_pair(n, n)."""
+    from oracle import pyoracle as orc
+    P, Q = synth.make_pair(n, n)
+    last = max(iters_at)
+    tr = orc.icp(P, Q, last, trace=True, trace_p=True, nthreads=threads) if last > 0 else None
+    Qc = orc.mean0(Q)
+    Qz = orc.sub_row(Q, Qc)
+    rows = np.sort(np.random.RandomState(n % 1000003).choice(n, n_rows, replace=False)).astype(np.int64)
+    out = {"n": np.int64(n), "rows": rows, "iters_at": np.array(iters_at, dtype=np.int32), "Qc": Qc}
+    with tempfile.TemporaryDirectory() as td:
+        qf = os.path.join(td, "Q.csv")
+        write_csv(qf, Qz)
+        for k in iters_at:
+            Pk = P if k == 0 else (tr["P_in"][k] if k < last else tr["P_out"])
+            Pc = orc.mean0(Pk)
+            Pz = orc.sub_row(Pk[rows], Pc)
+            pf, of = os.path.join(td, "P%d.csv" % k), os.path.join(td, "idx%d.bin" % k)
+            write_csv(pf, Pz)
+            subprocess.check_call([TRACE, "--corr", pf, qf, of])
+            idx = np.fromfile(of, dtype=np.int32)
+            assert len(idx) == n_rows
+            port = orc.correspondences(Pz, Qz, nthreads=threads)
+            assert np.array_equal(idx, port), "oracle port differs from the reference at full size"
+            out["P_rows_%d" % k] = Pk[rows].copy()
+            out["Pc_%d" % k] = Pc
+            out["idx_%d" % k] = idx
+            if k > 0:
+                out["seed_%d" % k] = tr["idx"][k - 1][rows].copy()
+            print("%-14s iteration %d: %d rows x %d targets through the reference" % (name, k, n_rows, n), flush=True)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+
+
+# BASELINE configs[2] (100k x 100k, 30 iterations): iterations 1, 15 and 30
+@case
+def syn100k_rows():
+    run_rows_case("syn100k_rows", 100000, [0, 14, 29], 2000, int(os.environ.get("GOLDEN_THREADS", "8")))
+
+
+# BASELINE configs[3] (1M x 1M): iteration 1 (un-seeded) and iteration 3 (seeded)
+@case
+def syn1m_rows():
+    run_rows_case("syn1m_rows", 1000000, [0, 2], 400, int(os.environ.get("GOLDEN_THREADS", "8")))
 
 
 if __name__ == "__main__":

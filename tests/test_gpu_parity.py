@@ -498,6 +498,12 @@ def test_filter_variants_nonfinite_and_outliers(matrix_pipe, monkeypatch):
     Pn = Pz.copy()
     Pn[5, 0], Pn[17, 1], Pn[99, 2], Pn[640] = np.nan, np.inf, -np.inf, 1e200
     cases["source"] = (Pn, Qz)
+    # source rows far outside the filters' range whose exact d^2 is still finite: the fp32 products p x (-2q) overflow
+    # (|p| 2|q| > 3.4e38) although the row has a perfectly good nearest neighbour
+    Pf = Pz.copy()
+    Pf[3], Pf[70, 1], Pf[1234, 2], Pf[2999] = 1e30, -3e38, 7e60, (1e100, -1e100, 1e100)
+    cases["source_far_finite"] = (Pf, Qz * 1e9)
+    cases["source_far_finite_big_targets"] = (Pf, Qz * 1e14)
     for name, vals in (("target_inf", (np.inf, np.nan)), ("target_huge", (1e19, -3e25)), ("target_tiny", (1e-300, 5e-324))):
         Qn = Qz.copy()
         Qn[7, 1], Qn[4000, 0] = vals

@@ -107,22 +107,30 @@ def test_torch_stream_and_single_rank_process_group():
 
 
 def test_bench_two_ranks_on_one_gpu_over_gloo():
-    """bench.py's multi-rank path end to end (torch.distributed.run, 2 processes, ShardedIcp with caller-owned exchange
-    buffers on its own stream) rehearsed on the one GPU of this box with the gloo backend standing in for RCCL."""
+    """bench.py's multi-rank path end to end, started the way the driver starts it -- `python bench.py --gpus 2` with no
+    torchrun around it: bench.py launches its own torch.distributed.run child (2 processes, ShardedIcp with caller-owned
+    exchange buffers on its own stream) before it touches the GPU, and relays rank 0's line.  Rehearsed on the one GPU of
+    this box with the gloo backend standing in for RCCL."""
     import json
     import os
     import subprocess
     import sys
     from conftest import ROOT
     env = dict(os.environ, ICP_AMD_BENCH_DEVICE="0", ICP_AMD_BENCH_BACKEND="gloo", OMP_NUM_THREADS="4")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29577", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-           "--src", "60000", "--tgt", "50000"]
+    env.pop("WORLD_SIZE", None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--src", "60000", "--tgt", "50000", "--n1-value", "1e12"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=280)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
-    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
-    d = json.loads(line)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["parallelism"] == "p-shard2"
+    assert d["process_group"] == {"ranks": 2, "backend": "gloo"} and d["rccl_ranks"] == 0   # gloo rehearsal: no RCCL rank
+    assert len(d["search_ms_per_rank"]["values"]) == 2 and d["search_ms_per_rank"]["min"] > 0
+    assert set(d["collective_ms"]) == {"cov_partials", "centroid_partials"}
+    assert d["rt_crosscheck"]["ranks_identical_to_rank0"] == 2      # every rank solved the same R, t, bit for bit
+    assert d["first_step_ms"] > 0 and abs(d["scaling_vs_n1"] - d["value"] / 2e12) < 1e-12
     assert d["config"]["search"]["variant"] == "f32" and d["grid_search"]["search"]["variant"] == "grid"
     assert d["grid_search"]["iters_per_sec"] > 0
     # same workload on one rank: the registration must reach the same rms (bit-identical results whatever the sharding)
