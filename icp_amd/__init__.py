@@ -266,6 +266,19 @@ def correspondences(P, Pc, Qz, search="exact", q_splits=1):
     return idx
 
 
+def correspondences_seeded(P, Pc, Qz, seed, search="f32", q_splits=1):
+    """icp_amd_correspondences_seeded: the same search started from candidate correspondences (the seeded kernels)."""
+    P, Qz = _f64(P), _f64(Qz)
+    Pc = np.ascontiguousarray(Pc, dtype=np.float64)
+    seed = np.ascontiguousarray(seed, dtype=np.int32)
+    if seed.shape != (P.shape[0],):
+        raise IcpAmdError(_lib.EINVAL, "expected one seed per source row")
+    idx = np.empty(P.shape[0], dtype=np.int32)
+    check(lib().icp_amd_correspondences_seeded(_p(P), C.c_size_t(P.shape[0]), _p(Pc), _p(Qz), C.c_size_t(Qz.shape[0]),
+                                               C.c_int(SEARCH[search]), C.c_int(q_splits), _p(seed), _p(idx)))
+    return idx
+
+
 def cross_cov(P, Pc, Qz, idx):
     P, Qz = _f64(P), _f64(Qz)
     Pc = np.ascontiguousarray(Pc, dtype=np.float64)

@@ -1234,8 +1234,28 @@ int upload_soa(hipStream_t s, const double *host, size_t n, size_t n_pad, double
 }
 }  // namespace
 
+static int correspondences_impl(const double *P, size_t n, const double Pc[3], const double *Qz, size_t m, int search_variant,
+                                int q_splits, const int32_t *seed, int32_t *idx);
+
 extern "C" int icp_amd_correspondences(const double *P, size_t n, const double Pc[3], const double *Qz, size_t m, int search_variant,
                                        int q_splits, int32_t *idx)
+{
+    return correspondences_impl(P, n, Pc, Qz, m, search_variant, q_splits, nullptr, idx);
+}
+
+// The same call as a SEEDED launch: seed[i] = a candidate correspondence of row i (what an iteration of the loop hands to the
+// next one, src/gpu/icp.cu:548-628 keeps no such state); out-of-range entries mean "none".  Seeds change no result -- they
+// only start every row's running minimum low -- but they select the kernels' seeded code paths, which is what the
+// iterations after the first run.
+extern "C" int icp_amd_correspondences_seeded(const double *P, size_t n, const double Pc[3], const double *Qz, size_t m,
+                                              int search_variant, int q_splits, const int32_t *seed, int32_t *idx)
+{
+    if (!seed) return fail(ICP_AMD_EINVAL, "icp_amd_correspondences_seeded: NULL seed");
+    return correspondences_impl(P, n, Pc, Qz, m, search_variant, q_splits, seed, idx);
+}
+
+static int correspondences_impl(const double *P, size_t n, const double Pc[3], const double *Qz, size_t m, int search_variant,
+                                int q_splits, const int32_t *seed, int32_t *idx)
 {
     if (!P || !Pc || !Qz || !idx) return fail(ICP_AMD_EINVAL, "icp_amd_correspondences: NULL argument");
     if (n == 0 || m == 0 || n > kMaxRows || m > kMaxRows) return fail(ICP_AMD_EINVAL, "icp_amd_correspondences: bad sizes");
@@ -1248,6 +1268,14 @@ extern "C" int icp_amd_correspondences(const double *P, size_t n, const double P
     RCCHK(upload_soa(s, Qz, m, m_pad, std::numeric_limits<double>::infinity(), qst, qstage, dQ));
     HIPCHK(pc.alloc(3 * sizeof(double)));
     HIPCHK(hipMemcpyAsync(pc.p, Pc, 3 * sizeof(double), hipMemcpyHostToDevice, s));
+    DevBuf seeds;
+    const uint32_t *prev = nullptr;
+    if (seed) {   // n_pad entries, "none" beyond the n rows
+        HIPCHK(seeds.alloc(n_pad * sizeof(uint32_t)));
+        HIPCHK(hipMemsetAsync(seeds.p, 0xFF, n_pad * sizeof(uint32_t), s));
+        HIPCHK(hipMemcpyAsync(seeds.p, seed, n * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+        prev = seeds.as<uint32_t>();
+    }
     const bool f32 = search_variant == ICP_AMD_SEARCH_F32;
     const size_t max_splits = search_scan_rows(m) / kSplitGran;
     if (q_splits < 1) q_splits = 1;
@@ -1274,7 +1302,7 @@ extern "C" int icp_amd_correspondences(const double *P, size_t n, const double P
         struct ScratchHolder { GridScratch sc; ~ScratchHolder() { grid_scratch_free(&sc); } } sh;
         HIPCHK(grid_scratch_alloc(s, n, &sh.sc));
         HIPCHK(grec.alloc(n_pad * sizeof(double2)));
-        HIPCHK(search_grid(s, dP, n, pc.as<double>(), gh.g, dQ, m, nullptr, nullptr, &sh.sc, grec.as<double2>()));
+        HIPCHK(search_grid(s, dP, n, pc.as<double>(), gh.g, dQ, m, prev, nullptr, &sh.sc, grec.as<double2>()));
         HIPCHK(hipStreamSynchronize(s));   // the scratch is released on scope exit
     } else if (f32) {
         if (cb == 8) cb = 16;
@@ -1291,22 +1319,22 @@ extern "C" int icp_amd_correspondences(const double *P, size_t n, const double P
                 DevBuf rec16;
                 HIPCHK(rec16.alloc(32 * m_pad));
                 HIPCHK(build_qrec16(s, dQ, m, m_pad, sqrt(qmax2), rec16.p));
-                HIPCHK(search_mfma16(s, mfma_groups(n_pad), dP, n_pad, pc.as<double>(), dQ, rec16.p, sqrt(qmax2), m, m_pad, q_splits, nullptr,
+                HIPCHK(search_mfma16(s, mfma_groups(n_pad), dP, n_pad, pc.as<double>(), dQ, rec16.p, sqrt(qmax2), m, m_pad, q_splits, prev,
                                      keys.as<double>(), idxs.as<uint32_t>()));
                 HIPCHK(hipStreamSynchronize(s));   // rec16 is released on scope exit
             } else if (mfma_groups(n_pad))
-                HIPCHK(search_mfma(s, mfma_groups(n_pad), dP, n_pad, pc.as<double>(), dQ, qrec.p, sqrt(qmax2), m, m_pad, q_splits, nullptr,
+                HIPCHK(search_mfma(s, mfma_groups(n_pad), dP, n_pad, pc.as<double>(), dQ, qrec.p, sqrt(qmax2), m, m_pad, q_splits, prev,
                                    keys.as<double>(), idxs.as<uint32_t>()));
             else
-                HIPCHK(search_f32(s, ppl, cb, dP, n_pad, pc.as<double>(), dQ, qrec.p, sqrt(qmax2), m, m_pad, q_splits, nullptr,
+                HIPCHK(search_f32(s, ppl, cb, dP, n_pad, pc.as<double>(), dQ, qrec.p, sqrt(qmax2), m, m_pad, q_splits, prev,
                                   keys.as<double>(), idxs.as<uint32_t>()));
         } else {   // range outside the fp32 bound's domain: same degradation as the engine
             if (ppl == 8) ppl = 4;
-            HIPCHK(search(s, kFma, ppl, cb, dP, n_pad, pc.as<double>(), dQ, m, m_pad, q_splits, nullptr, keys.as<double>(),
+            HIPCHK(search(s, kFma, ppl, cb, dP, n_pad, pc.as<double>(), dQ, m, m_pad, q_splits, prev, keys.as<double>(),
                           idxs.as<uint32_t>()));
         }
     } else {
-        HIPCHK(search(s, variant, ppl, cb, dP, n_pad, pc.as<double>(), dQ, m, m_pad, q_splits, nullptr, keys.as<double>(),
+        HIPCHK(search(s, variant, ppl, cb, dP, n_pad, pc.as<double>(), dQ, m, m_pad, q_splits, prev, keys.as<double>(),
                       idxs.as<uint32_t>()));
     }
     HIPCHK(merge_cov(s, dP, n, n_pad, pc.as<double>(), dQ, m, q_splits, keys.as<double>(), idxs.as<uint32_t>(),

@@ -190,6 +190,12 @@ int icp_amd_run_batch(const double *P, const double *Q, size_t batch, size_t n, 
  * P (src/gpu/icp.cu:557) fused in: idx[i] = argmin_j key(P[i]-Pc, Qz[j]).  Qz is used as given. */
 int icp_amd_correspondences(const double *P_xyz, size_t n, const double Pc[3], const double *Qz_xyz, size_t m,
                             int search, int q_splits, int32_t *idx);
+/* The same as a seeded launch: seed[i] is a candidate correspondence of row i (an entry outside [0, m) means none), as the
+ * loop hands one iteration's result to the next (no counterpart in the reference, whose kernels start every scan from
+ * scratch, corresp_optimized.cu:42-47).  Same indices as the un-seeded call -- a seed only starts the row's running
+ * minimum low -- through the kernels' seeded code paths. */
+int icp_amd_correspondences_seeded(const double *P_xyz, size_t n, const double Pc[3], const double *Qz_xyz, size_t m,
+                                   int search, int q_splits, const int32_t *seed, int32_t *idx);
 /* get_array_cross_covs_flattened + reduce_0(SUM) (include/libgpuicp/crosscov.cuh:112-116, src/gpu/icp.cu:579-584) */
 int icp_amd_cross_cov(const double *P_xyz, size_t n, const double Pc[3], const double *Qz_xyz, size_t m,
                       const int32_t *idx, double cov[9]);
