@@ -231,6 +231,22 @@ def bench_batch(args, rank, world, local_rank):
     if rank == 0:
         pairs = float(args.batch) * n * n * args.batch_iters
         ach = FLOPS_PER_PAIR * float(hi - lo) * n * n * args.batch_iters / (kms / args.steps * 1e-3)
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            # the oracle port (the reference's loop, oracle/icp_oracle.c) on whole registrations of the same batch: each
+            # registration is independent, so the host cores take one each (OpenMP inside one 1k x 1k search does not pay)
+            from concurrent.futures import ThreadPoolExecutor
+            from oracle import pyoracle as orc
+            cores = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "0") or 0) or (os.cpu_count() or 1))
+            regs = max(64, 4 * cores)
+            t1 = time.perf_counter()
+            with ThreadPoolExecutor(cores) as ex:     # ctypes releases the GIL inside the C call
+                list(ex.map(lambda k: orc.icp(P[k % len(P)], Q[k % len(Q)], args.batch_iters, nthreads=1), range(regs)))
+            cdt = time.perf_counter() - t1
+            cpu = {"value": regs * float(n) * n * args.batch_iters / cdt, "unit": "distance evals/s", "cores": cores, "kind": "port",
+                   "registrations_per_sec": regs / cdt,
+                   "sample": "%d whole registrations (%d x %d, %d iterations) of the same batch, one per host thread, %.1f s"
+                             % (regs, n, n, args.batch_iters, cdt)}
         print(json.dumps({
             "metric": "distance_evals_per_sec", "value": pairs * args.steps / dt, "unit": "distance evals/s",
             "registrations_per_sec": args.batch * args.steps / dt, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -239,7 +255,15 @@ def bench_batch(args, rank, world, local_rank):
             "config": {"workload": "BASELINE configs[4]: %d registrations of %d x %d points, %d iterations each, %d per GPU"
                                    % (args.batch, n, n, args.batch_iters, hi - lo), "parallelism": "batch-split%d" % world},
             "roofline": {"bound": "valu_fp64", "kernel": "batch_icp_kernel", "achieved": ach / 1e12, "peak": PEAK_FP64_VALU_NOFMA / 1e12,
-                         "unit": "TFLOP/s", "frac": ach / PEAK_FP64_VALU_NOFMA, "avg_launch_ms": kms / args.steps, "traffic": None}}),
+                         "unit": "TFLOP/s", "frac": ach / PEAK_FP64_VALU_NOFMA, "avg_launch_ms": kms / args.steps,
+                         # one launch reads both clouds once and writes the registered cloud, the solve record and the
+                         # indices; everything else stays in LDS / registers.  Algorithmic bytes, not a counter reading.
+                         "algorithmic_bytes": float(hi - lo) * (n * 24 * 2 + n * 24 + n * 4 + 28 * 8),
+                         "traffic": None,
+                         "note": "8 un-fused fp64 flops per pair against the un-fused fp64 VALU peak; the kernel's default form "
+                                 "issues 7 fp64 instructions per pair (3 FMA), so frac can approach 8/7"},
+            "cpu_baseline": cpu,
+            "gpu_over_cpu": (pairs * args.steps / dt) / cpu["value"] if cpu else None}),
             flush=True)
     b.close()
     if world > 1:

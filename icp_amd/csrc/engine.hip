@@ -51,6 +51,15 @@ extern "C" int icp_amd_device_count(void)
     return n;
 }
 
+// hipGetLastError() is sticky per host thread and shared with every other HIP user of the process (torch, RCCL, an earlier
+// failed call): a stale error there would be reported by the next launch wrapper's `return hipGetLastError()` as if the
+// launch had failed.  Every entry point selects its device through this, which drops whatever was left behind first.
+static hipError_t set_device(int device)
+{
+    (void)hipGetLastError();
+    return hipSetDevice(device);
+}
+
 static int require_device(int device)
 {
     int n = 0;
@@ -59,7 +68,7 @@ static int require_device(int device)
         return fail(ICP_AMD_ENODEV, "no HIP device available (%s); libicp_amd has no CPU fallback",
                     e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
     if (device < 0 || device >= n) return fail(ICP_AMD_EINVAL, "device %d out of range [0,%d)", device, n);
-    HIPCHK(hipSetDevice(device));
+    HIPCHK(set_device(device));
     return ICP_AMD_OK;
 }
 
@@ -263,7 +272,7 @@ extern "C" int icp_amd_set_target(icp_amd_engine *e, const double *Q, size_t m)
     if (!e || !Q) return fail(ICP_AMD_EINVAL, "icp_amd_set_target: NULL argument");
     if (m == 0) return fail(ICP_AMD_EINVAL, "target cloud is empty");
     if (m > kMaxRows) return fail(ICP_AMD_EINVAL, "target cloud too large (%zu rows, limit %zu)", m, kMaxRows);
-    HIPCHK(hipSetDevice(e->opt.device));
+    HIPCHK(set_device(e->opt.device));
     const size_t m_pad = round_up(m, kPadRows);
     if (m_pad != e->m_pad) {
         free_dev(e, e->q_store); free_dev(e, e->qrec); free_dev(e, e->q_rec); free_dev(e, e->qrec16);
@@ -471,7 +480,7 @@ extern "C" int icp_amd_set_source(icp_amd_engine *e, const double *P, size_t n)
     const size_t expect = first >= n_global ? 0 : ((n_global - first < cpr * kChunk) ? n_global - first : cpr * kChunk);
     if (n != expect)
         return fail(ICP_AMD_EINVAL, "rank %d of %d must own %zu source rows (got %zu)", e->opt.rank, world, expect, n);
-    HIPCHK(hipSetDevice(e->opt.device));
+    HIPCHK(set_device(e->opt.device));
     const size_t n_pad = round_up(n ? n : 1, kPadRows);
     if (n_pad != e->n_pad) {
         free_dev(e, e->p_store); free_dev(e, e->idx); free_dev(e, e->order);
@@ -526,7 +535,7 @@ extern "C" int icp_amd_set_source(icp_amd_engine *e, const double *P, size_t n)
 extern "C" int icp_amd_step_begin(icp_amd_engine *e)
 {
     if (!e || !e->have_source) return fail(ICP_AMD_ESTATE, "icp_amd_step_begin: no source cloud");
-    HIPCHK(hipSetDevice(e->opt.device));
+    HIPCHK(set_device(e->opt.device));
     double *cen_slot = e->cen_part + (size_t)e->opt.rank * e->cpr * kCenW;
     HIPCHK(colsum_partials(e->stream, nullptr, e->P, e->n, cen_slot));
     e->cen_ready = true;
@@ -566,7 +575,7 @@ extern "C" int icp_amd_step_search(icp_amd_engine *e)
 {
     if (!e || !e->have_source) return fail(ICP_AMD_ESTATE, "icp_amd_step_search: no source cloud");
     if (!e->cen_ready) return fail(ICP_AMD_ESTATE, "icp_amd_step_search: centroid partials missing (step_begin / step_update first)");
-    HIPCHK(hipSetDevice(e->opt.device));
+    HIPCHK(set_device(e->opt.device));
     // P_center = P_copy.mean(0) (src/cpu/icp.cpp:206): chunk partials of every rank, summed in index order
     HIPCHK(finalize_centroid(e->stream, e->cen_part, e->total_chunks, (double)e->n_global, e->pc));
     double *cov_slot = e->cov_part + (size_t)e->opt.rank * e->cpr * kCovW;
@@ -589,7 +598,28 @@ extern "C" int icp_amd_step_search(icp_amd_engine *e)
             }
             if (e->bf_left) { --e->bf_left; grid = false; }
         }
-        const int splits = grid ? 1 : (seed ? e->q_splits : e->q_splits_first);
+        // A brute-force launch without a previous correspondence (the first iteration of a run) re-learns every row's
+        // running minimum ~ln(M) times on its exact path: 60 ms against 27 ms seeded at 1M x 1M.  Where a grid can be had,
+        // its exact answer (0.5 ms) is that seed; the brute-force launch still evaluates every pair.  ICP_AMD_GRID_SEED=0
+        // keeps the un-seeded launch (tests of that code path).
+        bool grid_seeded = false;
+        if (!grid && !seed && e->seed_enabled && e->m >= kAutoGridMinTargets && !e->P.rec && env_int("ICP_AMD_GRID_SEED", 1)) {
+            if (!e->grid_built) {
+                HIPCHK(grid_build(e->stream, e->Qz, e->m, &e->grid));
+                e->grid_built = true;
+            }
+            if (e->grid.ok) {
+                if (!e->gscratch.list) HIPCHK(grid_scratch_alloc(e->stream, e->n_pad, &e->gscratch));
+                if (!e->grid_out) HIPCHK(dmalloc(&e->grid_out, e->n_pad * sizeof(double2)));
+                HIPCHK(search_grid(e->stream, e->P, e->n, e->pc, e->grid, e->Qz, e->m, nullptr, nullptr, &e->gscratch, e->grid_out));
+                // idx <- the grid's correspondences (the partial sums this also writes are overwritten below)
+                HIPCHK(merge_cov(e->stream, e->P, e->n, e->n_pad, e->pc, e->Qz, e->m, 1, nullptr, nullptr, e->grid_out, false, e->idx,
+                                 e->reject_d2, cov_slot));
+                grid_seeded = true;
+            }
+        }
+        const bool seeded = seed || grid_seeded;
+        const int splits = grid ? 1 : (seeded ? e->q_splits : e->q_splits_first);
         if (!grid) RCCHK(ensure_split_buffers(e));
         if (grid) ++e->grid_launches; else ++e->bf_launches;
         if (grid)
@@ -602,16 +632,16 @@ extern "C" int icp_amd_step_search(icp_amd_engine *e)
                 e->qrec16_ok = true;
             }
             HIPCHK(search_mfma16(e->stream, e->mfma_g, e->P, e->n_pad, e->pc, e->Qz, e->qrec16, e->qmax, e->m, e->m_pad, splits,
-                                 seed ? e->idx : nullptr, e->keys, e->idxs));
+                                 seeded ? e->idx : nullptr, e->keys, e->idxs));
         } else if (e->variant == kF32 && e->mfma_g)
             HIPCHK(search_mfma(e->stream, e->mfma_g, e->P, e->n_pad, e->pc, e->Qz, e->qrec, e->qmax, e->m, e->m_pad, splits,
-                               seed ? e->idx : nullptr, e->keys, e->idxs));
+                               seeded ? e->idx : nullptr, e->keys, e->idxs));
         else if (e->variant == kF32)
             HIPCHK(search_f32(e->stream, e->ppl, e->cb, e->P, e->n_pad, e->pc, e->Qz, e->qrec, e->qmax, e->m, e->m_pad, splits,
-                              seed ? e->idx : nullptr, e->keys, e->idxs));
+                              seeded ? e->idx : nullptr, e->keys, e->idxs));
         else
             HIPCHK(search(e->stream, e->variant, e->ppl, e->cb, e->P, e->n_pad, e->pc, e->Qz, e->m, e->m_pad, splits,
-                          seed ? e->idx : nullptr, e->keys, e->idxs));
+                          seeded ? e->idx : nullptr, e->keys, e->idxs));
         if (e->opt.kernel_timing) HIPCHK(hipEventRecord(b, e->stream));
         HIPCHK(merge_cov(e->stream, e->P, e->n, e->n_pad, e->pc, e->Qz, e->m, splits, e->keys, e->idxs,
                          grid && !e->P.rec ? e->grid_out : nullptr, grid && e->P.rec, e->idx, e->reject_d2, cov_slot));
@@ -623,7 +653,7 @@ extern "C" int icp_amd_step_search(icp_amd_engine *e)
 extern "C" int icp_amd_step_update(icp_amd_engine *e)
 {
     if (!e || !e->have_source) return fail(ICP_AMD_ESTATE, "icp_amd_step_update: no source cloud");
-    HIPCHK(hipSetDevice(e->opt.device));
+    HIPCHK(set_device(e->opt.device));
     const bool rejecting = e->reject_d2 < std::numeric_limits<double>::infinity();
     HIPCHK(solve(e->stream, e->cov_part, e->total_chunks, e->pc, e->qc, rejecting ? -1.0 : (double)e->n_global, e->rec,
                  e->rec + kSolveW));
@@ -659,7 +689,7 @@ extern "C" int icp_amd_set_reject_distance(icp_amd_engine *e, double dmax)
 extern "C" int icp_amd_get_last_motion(icp_amd_engine *e, double *pairs_used, double *delta_rot, double *delta_trans)
 {
     if (!e) return fail(ICP_AMD_EINVAL, "icp_amd_get_last_motion: NULL engine");
-    HIPCHK(hipSetDevice(e->opt.device));
+    HIPCHK(set_device(e->opt.device));
     double h[3];
     HIPCHK(hipMemcpyAsync(h, e->rec + kSolveW, sizeof h, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
@@ -694,7 +724,7 @@ extern "C" int icp_amd_iterate_until(icp_amd_engine *e, unsigned max_iters, doub
 extern "C" int icp_amd_iterate_timed(icp_amd_engine *e, unsigned iters, double *elapsed_ms)
 {
     if (!e) return fail(ICP_AMD_EINVAL, "icp_amd_iterate_timed: NULL engine");
-    HIPCHK(hipSetDevice(e->opt.device));
+    HIPCHK(set_device(e->opt.device));
     if (iters && !e->cen_ready && e->have_source) RCCHK(icp_amd_step_begin(e));
     hipEvent_t a, b;
     HIPCHK(hipEventCreate(&a));
@@ -717,7 +747,7 @@ extern "C" int icp_amd_iterate_timed(icp_amd_engine *e, unsigned iters, double *
 extern "C" int icp_amd_sync(icp_amd_engine *e)
 {
     if (!e) return fail(ICP_AMD_EINVAL, "icp_amd_sync: NULL engine");
-    HIPCHK(hipSetDevice(e->opt.device));
+    HIPCHK(set_device(e->opt.device));
     HIPCHK(hipStreamSynchronize(e->stream));
     return ICP_AMD_OK;
 }
@@ -726,7 +756,7 @@ extern "C" int icp_amd_get_source(icp_amd_engine *e, double *P_out)
 {
     if (!e || (!P_out && e->n)) return fail(ICP_AMD_EINVAL, "icp_amd_get_source: NULL argument");
     if (!e->have_source) return fail(ICP_AMD_ESTATE, "icp_amd_get_source: no source cloud");
-    HIPCHK(hipSetDevice(e->opt.device));
+    HIPCHK(set_device(e->opt.device));
     if (e->n) {
         RCCHK(ensure_stage(e, e->n));
         HIPCHK(soa_to_aos(e->stream, e->P, e->n, e->stage));
@@ -740,7 +770,7 @@ extern "C" int icp_amd_get_last(icp_amd_engine *e, double *Pc, int32_t *idx, dou
                                 double *rms)
 {
     if (!e) return fail(ICP_AMD_EINVAL, "icp_amd_get_last: NULL engine");
-    HIPCHK(hipSetDevice(e->opt.device));
+    HIPCHK(set_device(e->opt.device));
     double rec[kSolveW];
     HIPCHK(hipMemcpyAsync(rec, e->rec, sizeof rec, hipMemcpyDeviceToHost, e->stream));
     if (idx && e->n) HIPCHK(hipMemcpyAsync(idx, e->idx, e->n * sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
@@ -757,7 +787,7 @@ extern "C" int icp_amd_get_last(icp_amd_engine *e, double *Pc, int32_t *idx, dou
 extern "C" int icp_amd_get_target_centroid(icp_amd_engine *e, double Qc[3])
 {
     if (!e || !Qc || !e->have_target) return fail(ICP_AMD_ESTATE, "icp_amd_get_target_centroid: no target cloud");
-    HIPCHK(hipSetDevice(e->opt.device));
+    HIPCHK(set_device(e->opt.device));
     HIPCHK(hipMemcpyAsync(Qc, e->qc, 3 * sizeof(double), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
     return ICP_AMD_OK;
@@ -766,7 +796,7 @@ extern "C" int icp_amd_get_target_centroid(icp_amd_engine *e, double Qc[3])
 extern "C" int icp_amd_kernel_ms(icp_amd_engine *e, double *avg_ms, double *total_ms, unsigned *launches)
 {
     if (!e) return fail(ICP_AMD_EINVAL, "icp_amd_kernel_ms: NULL engine");
-    HIPCHK(hipSetDevice(e->opt.device));
+    HIPCHK(set_device(e->opt.device));
     HIPCHK(hipStreamSynchronize(e->stream));
     RCCHK(drain_events(e));
     if (avg_ms) *avg_ms = e->search_launches ? e->search_ms_total / e->search_launches : 0.0;
@@ -898,11 +928,11 @@ int all_gather_by_copies(MultiRun &r, std::vector<double *> &buf, size_t per)
 {
     const int G = (int)r.eng.size();
     for (int g = 0; g < G; ++g) {
-        HIPCHK(hipSetDevice(r.dev[g]));
+        HIPCHK(set_device(r.dev[g]));
         HIPCHK(hipEventRecord(r.ready[g], r.eng[g]->stream));
     }
     for (int g = 0; g < G; ++g) {
-        HIPCHK(hipSetDevice(r.dev[g]));
+        HIPCHK(set_device(r.dev[g]));
         for (int h = 0; h < G; ++h) {
             if (h == g) continue;
             HIPCHK(hipStreamWaitEvent(r.eng[g]->stream, r.ready[h], 0));
@@ -913,7 +943,7 @@ int all_gather_by_copies(MultiRun &r, std::vector<double *> &buf, size_t per)
     }
     // nobody overwrites its slot (the next iteration's partials) before every reader has copied it
     for (int h = 0; h < G; ++h) {
-        HIPCHK(hipSetDevice(r.dev[h]));
+        HIPCHK(set_device(r.dev[h]));
         for (int g = 0; g < G; ++g)
             if (g != h) HIPCHK(hipStreamWaitEvent(r.eng[h]->stream, r.done[g], 0));
     }
@@ -986,7 +1016,7 @@ extern "C" int icp_amd_run_multi(const double *P, size_t n, const double *Q, siz
         r.ready.assign(G, nullptr);
         r.done.assign(G, nullptr);
         for (int g = 0; g < G; ++g) {
-            HIPCHK(hipSetDevice(r.dev[g]));
+            HIPCHK(set_device(r.dev[g]));
             HIPCHK(hipEventCreateWithFlags(&r.ready[g], hipEventDisableTiming));
             HIPCHK(hipEventCreateWithFlags(&r.done[g], hipEventDisableTiming));
             for (int h = 0; h < G; ++h) {   // peer access where the copies cross devices (already enabled is fine)
@@ -1099,7 +1129,7 @@ extern "C" int icp_amd_batch_create(icp_amd_batch **out, int device, size_t batc
 extern "C" int icp_amd_batch_upload(icp_amd_batch *b, const double *P, const double *Q)
 {
     if (!b || !P || !Q) return fail(ICP_AMD_EINVAL, "icp_amd_batch_upload: NULL argument");
-    HIPCHK(hipSetDevice(b->device));
+    HIPCHK(set_device(b->device));
     HIPCHK(hipMemcpyAsync(b->P_in, P, b->batch * b->n * 3 * sizeof(double), hipMemcpyHostToDevice, b->stream));
     HIPCHK(hipMemcpyAsync(b->Q_in, Q, b->batch * b->m * 3 * sizeof(double), hipMemcpyHostToDevice, b->stream));
     HIPCHK(hipStreamSynchronize(b->stream));
@@ -1112,7 +1142,7 @@ extern "C" int icp_amd_batch_run(icp_amd_batch *b, unsigned iters, int search_va
 {
     if (!b) return fail(ICP_AMD_EINVAL, "icp_amd_batch_run: NULL handle");
     if (!b->uploaded) return fail(ICP_AMD_ESTATE, "icp_amd_batch_run: upload the clouds first");
-    HIPCHK(hipSetDevice(b->device));
+    HIPCHK(set_device(b->device));
     // EXACT / FMA: the difference form on SoA targets; anything else (AUTO, F32, GRID): the expanded form on records
     int variant = search_variant == ICP_AMD_SEARCH_EXACT ? kExact : search_variant == ICP_AMD_SEARCH_FMA ? kFma : kExpanded;
     const char *sv = search_variant == ICP_AMD_SEARCH_AUTO ? getenv("ICP_AMD_SEARCH") : nullptr;   // an explicit variant wins
@@ -1143,7 +1173,7 @@ extern "C" int icp_amd_batch_download(icp_amd_batch *b, double *P_out, double *R
 {
     if (!b) return fail(ICP_AMD_EINVAL, "icp_amd_batch_download: NULL handle");
     if (!b->ran) return fail(ICP_AMD_ESTATE, "icp_amd_batch_download: nothing has run");
-    HIPCHK(hipSetDevice(b->device));
+    HIPCHK(set_device(b->device));
     std::vector<double> rec;
     if (P_out) HIPCHK(hipMemcpyAsync(P_out, b->P_out, b->batch * b->n * 3 * sizeof(double), hipMemcpyDeviceToHost, b->stream));
     if (idx) HIPCHK(hipMemcpyAsync(idx, b->idx, b->batch * b->n * sizeof(uint32_t), hipMemcpyDeviceToHost, b->stream));
@@ -1296,6 +1326,23 @@ static int correspondences_impl(const double *P, size_t n, const double Pc[3], c
     if (grid) {
         HIPCHK(grid_build(s, dQ, m, &gh.g));
         grid = gh.g.ok;   // non-finite target coordinates: brute force below, like the engine
+    }
+    if (!grid && !prev && search_variant != ICP_AMD_SEARCH_GRID && m >= kAutoGridMinTargets && env_int("ICP_AMD_GRID_SEED", 1)) {
+        // like the engine's first iteration: the grid's exact answer seeds the brute-force scan (which still evaluates
+        // every pair); targets the grid cannot file (non-finite coordinates) leave the launch un-seeded
+        HIPCHK(grid_build(s, dQ, m, &gh.g));
+        if (gh.g.ok) {
+            struct ScratchHolder { GridScratch sc; ~ScratchHolder() { grid_scratch_free(&sc); } } sh;
+            HIPCHK(grid_scratch_alloc(s, n, &sh.sc));
+            HIPCHK(grec.alloc(n_pad * sizeof(double2)));
+            HIPCHK(seeds.alloc(n_pad * sizeof(uint32_t)));
+            HIPCHK(hipMemsetAsync(seeds.p, 0xFF, n_pad * sizeof(uint32_t), s));
+            HIPCHK(search_grid(s, dP, n, pc.as<double>(), gh.g, dQ, m, nullptr, nullptr, &sh.sc, grec.as<double2>()));
+            HIPCHK(merge_cov(s, dP, n, n_pad, pc.as<double>(), dQ, m, 1, nullptr, nullptr, grec.as<double2>(), false, seeds.as<uint32_t>(),
+                             std::numeric_limits<double>::infinity(), part.as<double>()));
+            HIPCHK(hipStreamSynchronize(s));   // the scratch is released on scope exit
+            prev = seeds.as<uint32_t>();
+        }
     }
     if (grid) {
         q_splits = 1;

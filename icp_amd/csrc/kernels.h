@@ -15,7 +15,7 @@ constexpr int kCenW    = 3;      // doubles per centroid partial
 
 enum SearchVariant { kExact = 1, kFma = 2, kF32 = 3, kGrid = 4, kExpanded = 5 /* batch mode only */ };
 constexpr size_t kPadRows = 2048;  // clouds are padded to this many rows (covers every kernel's tile)
-constexpr size_t kSplitGran = 64;  // target splits are whole multiples of this many targets (>= every cb, even)
+constexpr size_t kSplitGran = 128; // target splits are whole multiples of this many targets (>= every kernel's event-check block)
 
 // Device memory through a small cache (devmem.cpp): same contracts as hipMalloc / hipFree, but released blocks are kept
 // (ICP_AMD_CACHE_MB, default 2048) and reused by later requests of about the same size.

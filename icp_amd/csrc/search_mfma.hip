@@ -177,6 +177,18 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(2))) void s
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 double search_mfma16_scale(double qmax);
 
+// LEAN operands: 11 of the 16 K slots carry a product, 5 are zero in BOTH operands -- the three lo x lo products
+// (each <= 2^-22 |T_c| |P_c|) and the third piece of W (W0 + W1 hold 22 bits) are dropped.  Their sum stays inside the SAME
+// bound E': piece truncation 2^-21 |P||T| + dropped lo x lo 2^-22 |P||T| + fp32 accumulation of 11 terms 11 * 2^-23
+// (|P||T| + W) + W's truncation 2^-22 W  =  8.5 * 2^-22 |P||T| + 7.5 * 2^-22 W  <  2^-18 (|P||T| + W).
+// Why: the kernel is POWER bound, not issue bound -- the chip lowers its clock to 1.6-1.9 GHz under random fp16 MFMA
+// operands and holds 2.39 GHz on zeros (tools/ubench_mfma.hip, profiles/r2_ubench_mfma.txt), so every multiplier that
+// sees a zero buys clock.
+#ifndef ICPK_LEAN
+#define ICPK_LEAN 1
+#endif
+constexpr bool kLean = ICPK_LEAN != 0;
+
 struct __attribute__((aligned(16))) Half8 { _Float16 v[8]; };
 
 __device__ __forceinline__ void split16(double v, _Float16 &hi, _Float16 &lo)
@@ -198,15 +210,15 @@ __global__ __launch_bounds__(kWG) void build_qrec16_kernel(const double *__restr
     if (i < m) {
         const double x = qx[i], y = qy[i], z = qz[i];
         _Float16 h, l;
-        split16(-2.0 * sigma * x, h, l); a.v[0] = a.v[1] = h; a.v[2] = a.v[3] = l;
-        split16(-2.0 * sigma * y, h, l); a.v[4] = a.v[5] = h; a.v[6] = a.v[7] = l;
-        split16(-2.0 * sigma * z, h, l); b.v[0] = b.v[1] = h; b.v[2] = b.v[3] = l;
+        split16(-2.0 * sigma * x, h, l); a.v[0] = a.v[1] = h; a.v[2] = l; a.v[3] = kLean ? (_Float16)0.0f : l;
+        split16(-2.0 * sigma * y, h, l); a.v[4] = a.v[5] = h; a.v[6] = l; a.v[7] = kLean ? (_Float16)0.0f : l;
+        split16(-2.0 * sigma * z, h, l); b.v[0] = b.v[1] = h; b.v[2] = l; b.v[3] = kLean ? (_Float16)0.0f : l;
         const double w = sigma * sigma * ((x * x + y * y) + z * z);
         const _Float16 w0 = (_Float16)(float)w;
         const double r1 = w - (double)(float)w0;
         const _Float16 w1 = (_Float16)(float)r1;
         const _Float16 w2 = (_Float16)(float)(r1 - (double)(float)w1);
-        b.v[4] = w0; b.v[5] = w1; b.v[6] = w2;
+        b.v[4] = w0; b.v[5] = w1; b.v[6] = kLean ? (_Float16)0.0f : w2;
     } else {
         b.v[4] = (_Float16)INFINITY;
     }
@@ -221,7 +233,12 @@ __device__ __forceinline__ double mfma16_bound(double pl, double tmax, double wm
 }
 
 constexpr int kTileQH = 1024;   // targets per LDS tile (2 x 16 KB)
-constexpr int kRowsH = 64;      // targets between event checks of the fp16 filter = two MFMA blocks (= kSplitGran)
+#ifndef ICPK_ROWSH
+#define ICPK_ROWSH 64
+#endif
+constexpr int kRowsH = ICPK_ROWSH;   // targets between event checks of the seeded launches (64 or 128; <= kSplitGran)
+constexpr int kRowsCoop = 64;        // ... of the un-seeded launches: the cooperative exact path maps lane u to target u
+static_assert((kRowsH == 64 || kRowsH == 128) && (size_t)kRowsH <= kSplitGran, "event-check blocks must tile a target split");
 
 #ifndef ICPK_COOPMAX
 #define ICPK_COOPMAX 8
@@ -257,6 +274,7 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(4))) void s
     const unsigned q1 = (q0 + q_per_split < m_scan) ? (q0 + q_per_split) : m_scan;
     const double s2 = sigma * sigma, tmax = 2.0 * sigma * qmax, wmax = s2 * qmax * qmax;
 
+    constexpr int ROWS = COOP ? kRowsCoop : kRowsH;
     f16x8 b[G];
     float ms[G], thr[G];
     double bd[G], bk[G];
@@ -279,11 +297,11 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(4))) void s
         split16(usable ? sigma * ay : 0.0, yh, yl);
         split16(usable ? sigma * az : 0.0, zh, zl);
         const _Float16 one = (_Float16)1.0f, zero = (_Float16)0.0f;
-        const f16x8 b0 = {xh, xl, xh, xl, yh, yl, yh, yl};
-        const f16x8 b1 = {zh, zl, zh, zl, one, one, one, zero};
+        const f16x8 b0 = {xh, xl, xh, kLean ? zero : xl, yh, yl, yh, kLean ? zero : yl};
+        const f16x8 b1 = {zh, zl, zh, kLean ? zero : zl, one, one, kLean ? zero : one, zero};
         b[g] = half ? b1 : b0;
         const uint32_t js = idx_prev ? idx_prev[row] : 0xFFFFFFFFu;
-        bd[g] = seed_init<kRowsH>(ax, ay, az, qx, qy, qz, js, m, q0, q1, bk[g], bj[g], sblk[g]);
+        bd[g] = seed_init<ROWS>(ax, ay, az, qx, qy, qz, js, m, q0, q1, bk[g], bj[g], sblk[g]);
         thr[g] = threshold(bd[g], pn);
         ms[g] = thr[g];
     }
@@ -297,33 +315,36 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(4))) void s
             st[1][k] = rec16[(size_t)m_pad + t0 + k];
         }
         __syncthreads();
-        // 64 targets between event checks: two MFMA rounds per source group, the operand of the next round already on
-        // its way from LDS while this one is reduced
+        // ROWS targets between event checks, in sub-blocks of 64: two MFMA rounds per source group and sub-block, the operand
+        // of the next round already on its way from LDS while this one is reduced
         f16x8 a_next = *(const f16x8 *)&sa[col];
-        for (int j0 = 0; j0 < cnt; j0 += kRowsH) {
-            const f16x8 a0 = a_next;
-            const f16x8 a1 = *(const f16x8 *)&sa[j0 + 32 + col];
-            a_next = *(const f16x8 *)&sa[(j0 + kRowsH < cnt ? j0 + kRowsH : 0) + col];
-            f32x16 acc[G];
-            const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        for (int j0 = 0; j0 < cnt; j0 += ROWS) {
 #pragma unroll
-            for (int g = 0; g < G; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b[g], zero, 0, 0, 0);
+            for (int sub = 0; sub < ROWS; sub += 64) {
+                const f16x8 a0 = a_next;
+                const f16x8 a1 = *(const f16x8 *)&sa[j0 + sub + 32 + col];
+                a_next = *(const f16x8 *)&sa[(j0 + sub + 64 < cnt ? j0 + sub + 64 : 0) + col];
+                f32x16 acc[G];
+                const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-            for (int g = 0; g < G; ++g) {
-                float v = ms[g];
+                for (int g = 0; g < G; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b[g], zero, 0, 0, 0);
 #pragma unroll
-                for (int r = 0; r < 16; r += 2) v = vmin3f(v, acc[g][r], acc[g][r + 1]);
-                ms[g] = v;
-                acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b[g], zero, 0, 0, 0);
+                for (int g = 0; g < G; ++g) {
+                    float v = ms[g];
+#pragma unroll
+                    for (int r = 0; r < 16; r += 2) v = vmin3f(v, acc[g][r], acc[g][r + 1]);
+                    ms[g] = v;
+                    acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b[g], zero, 0, 0, 0);
+                }
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    float v = ms[g];
+#pragma unroll
+                    for (int r = 0; r < 16; r += 2) v = vmin3f(v, acc[g][r], acc[g][r + 1]);
+                    ms[g] = v;
+                }
             }
-#pragma unroll
-            for (int g = 0; g < G; ++g) {
-                float v = ms[g];
-#pragma unroll
-                for (int r = 0; r < 16; r += 2) v = vmin3f(v, acc[g][r], acc[g][r + 1]);
-                ms[g] = v;
-            }
-            const unsigned blk = (t0 + (unsigned)j0) / kRowsH;
+            const unsigned blk = (t0 + (unsigned)j0) / ROWS;
             bool ev = false;
 #pragma unroll
             for (int g = 0; g < G; ++g) {
@@ -346,7 +367,7 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(4))) void s
                                 const double ax = px[row] - c0, ay = py[row] - c1, az = pz[row] - c2;
                                 const double pn = (ax * ax + ay * ay) + az * az;
                                 double dbest;
-                                rescan_block<kRowsH>(ax, ay, az, qx + jg, qy + jg, qz + jg, 0, jg, bd[g], bk[g], bj[g], dbest);
+                                rescan_block<ROWS>(ax, ay, az, qx + jg, qy + jg, qz + jg, 0, jg, bd[g], bk[g], bj[g], dbest);
                                 thr[g] = threshold(bd[g], pn);
                                 ms[g] = thr[g];
                             }
@@ -396,7 +417,7 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(4))) void s
                                     }
                                 } else {
                                     double dbest;
-                                    rescan_block<kRowsH>(ax, ay, az, qx + jg, qy + jg, qz + jg, 0, jg, bd[g], bk[g], bj[g], dbest);
+                                    rescan_block<ROWS>(ax, ay, az, qx + jg, qy + jg, qz + jg, 0, jg, bd[g], bk[g], bj[g], dbest);
                                 }
                                 thr[g] = threshold(bd[g], pn);
                                 ms[g] = thr[g];
@@ -414,7 +435,7 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(4))) void s
                             const double pn = (ax * ax + ay * ay) + az * az;
                             const unsigned jg = t0 + (unsigned)j0;
                             double dbest;
-                            rescan_block<kRowsH>(ax, ay, az, qx + jg, qy + jg, qz + jg, 0, jg, bd[g], bk[g], bj[g], dbest);
+                            rescan_block<ROWS>(ax, ay, az, qx + jg, qy + jg, qz + jg, 0, jg, bd[g], bk[g], bj[g], dbest);
                             thr[g] = threshold(bd[g], pn);
                             ms[g] = thr[g];
                         }
@@ -459,8 +480,8 @@ __global__ __launch_bounds__(64) void mfma16_probe_kernel(const double *__restri
     split16(sigma * ay, yh, yl);
     split16(sigma * az, zh, zl);
     const _Float16 one = (_Float16)1.0f, zero = (_Float16)0.0f;
-    const f16x8 b0 = {xh, xl, xh, xl, yh, yl, yh, yl};
-    const f16x8 b1 = {zh, zl, zh, zl, one, one, one, zero};
+    const f16x8 b0 = {xh, xl, xh, kLean ? zero : xl, yh, yl, yh, kLean ? zero : yl};
+    const f16x8 b1 = {zh, zl, zh, kLean ? zero : zl, one, one, kLean ? zero : one, zero};
     const f16x8 a = *(const f16x8 *)&rec16[(size_t)half * m_pad + j0 + col];
     const f32x16 zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     const f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, half ? b1 : b0, zero16, 0, 0, 0);

@@ -21,7 +21,7 @@ def golden(name):
         pytest.skip("golden fixture %s not present" % name)
     with np.load(path, allow_pickle=False) as z:
         g = {k: z[k] for k in z.files}
-    if "P_in_iters" in g and len(g["P_in_iters"]) and g["P_in_iters"][0] == 0:
+    if "P" in g and "P_in_iters" in g and len(g["P_in_iters"]) and g["P_in_iters"][0] == 0:
         # iteration 0 starts from P itself; make_golden.py does not store it twice
         g["P_in"] = np.concatenate([g["P"][None], g["P_in"].reshape(-1, *g["P"].shape)])
     return g

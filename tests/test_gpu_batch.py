@@ -153,3 +153,30 @@ def test_run_batch_takes_clouds_of_any_size(tmp_path):
     out, _ = icp_amd.read_cloud(tmp_path / "out.npy")
     for k in range(2):
         assert np.array_equal(out[k * 2500:(k + 1) * 2500], icp_amd.icp_gpu_optimized(Pc[k * 2500:(k + 1) * 2500], Qc[k * 2500:(k + 1) * 2500], 3)), k
+
+
+def test_config5_full_size_4096_registrations_of_1k_points_20_iterations():
+    """BASELINE configs[4] at its full size: 4096 registrations of 1000 x 1000 points, 20 iterations each, in ONE launch --
+    the grid dimension the benchmark launches (bench.py --workload batch builds the same clouds: 64 distinct pairs, tiled).
+    Every one of the 4096 results must equal the single-run result of its pair (icp_amd_run on that pair alone), bit for
+    bit; two pairs are also held against the oracle.  Reference semantics for the record: the reference's own `-batch`
+    (src/libgpuicp/batchcovs.cu:28-75) strip-mines ONE registration 16 source rows at a time -- it is not
+    multi-registration, so there is no reference vector for this mode beyond the per-pair results."""
+    batch, n, iters, distinct = 4096, 1000, 20, 64
+    P64, Q64 = synth.make_batch(distinct, n, seed=synth.SEED_Q)
+    reps = batch // distinct
+    P, Q = np.tile(P64, (reps, 1, 1)), np.tile(Q64, (reps, 1, 1))
+    out = icp_amd.icp_gpu_batch(P, Q, iters)
+    for b in range(distinct):
+        P_one, tr = icp_amd.icp_gpu_optimized(P64[b], Q64[b], iters, trace=True)
+        for r in range(reps):                       # every copy of the pair, wherever it sits in the launch
+            k = r * distinct + b
+            assert np.array_equal(out["idx"][k], tr["idx"][-1]), k
+            assert np.array_equal(out["P_out"][k], P_one), k
+            assert np.array_equal(out["R"][k], tr["R"][-1]) and np.array_equal(out["t"][k], tr["t"][-1]), k
+            assert np.array_equal(out["cov"][k], tr["cov"][-1]) and out["rms"][k] == tr["rms"][-1], k
+    for b in (0, 37):
+        ref = orc.icp(P64[b], Q64[b], iters, trace=True, nthreads=4)
+        assert np.array_equal(out["idx"][b], ref["idx"][-1])
+        assert relerr(out["R"][b], ref["R"][-1]) < 1e-9 and relerr(out["cov"][b], ref["cov"][-1]) < 1e-9
+        assert relerr(out["P_out"][b], ref["P_out"]) < 1e-9
