@@ -295,6 +295,19 @@ def centroid(A):
     return out
 
 
+def centroid_static(a_dev_ptr, n, out_dev_ptr, device=0, stream=None):
+    """icp_amd_centroid_static: the centroid of n x 3 device-resident rows into 3 device doubles, enqueued on `stream`,
+    without any allocation (static device scratch).  Pointers are raw device addresses (e.g. torch.Tensor.data_ptr())."""
+    check(lib().icp_amd_centroid_static(C.c_void_p(a_dev_ptr), C.c_size_t(n), C.c_void_p(out_dev_ptr), C.c_int(device),
+                                        C.c_void_p(stream)))
+
+
+def centroid_static_max_rows():
+    f = lib().icp_amd_centroid_static_max_rows
+    f.restype = C.c_size_t
+    return int(f())
+
+
 def solve(cov, Pc, Qc):
     cov = np.ascontiguousarray(cov, dtype=np.float64).reshape(9)
     Pc = np.ascontiguousarray(Pc, dtype=np.float64)

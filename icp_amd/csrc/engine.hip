@@ -15,6 +15,7 @@
 
 #include <algorithm>
 #include <limits>
+#include <mutex>
 #include <new>
 #include <string>
 #include <thread>
@@ -73,6 +74,7 @@ static int require_device(int device)
 }
 
 static int env_int(const char *name, int dflt);
+static int static_scratch(int device, double **out);
 
 // Context creation + code-object load, for callers that can overlap it with their own I/O.  One tiny launch per
 // translation unit with kernels (kernels.hip, grid.hip): HIP loads a unit's code object at its first launch.
@@ -87,6 +89,8 @@ extern "C" int icp_amd_init(int device)
     if (er == hipSuccess) er = hipStreamSynchronize(nullptr);
     (void)dfree(buf);
     HIPCHK(er);
+    double *sp = nullptr;
+    RCCHK(static_scratch(device < 0 ? env_int("ICP_AMD_DEVICE", 0) : device, &sp));   // icp_amd_centroid_static's scratch on this device
     return ICP_AMD_OK;
 }
 
@@ -1437,6 +1441,52 @@ extern "C" int icp_amd_centroid(const double *A, size_t n, double out[3])
     HIPCHK(finalize_centroid(s, part.as<double>(), chunks, (double)n, o.as<double>()));
     HIPCHK(hipMemcpyAsync(out, o.p, 3 * sizeof(double), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
+    return ICP_AMD_OK;
+}
+
+// ---- the entry point that allocates nothing (include/icp_amd.h): icp_amd_centroid on device-resident rows, with the chunk
+//      partials -- the scratch icp_amd_centroid allocates per call -- in a file-scope device array.  Every GPU the library
+//      runs on holds its own copy of the array until the process ends; its address on a device comes from
+//      hipGetSymbolAddress (with that device current), once per device, and only that address is ever handed to a kernel
+//      (the array's name is a host-side stand-in in host code, not a device address).
+static const size_t kStaticCentroidMaxRows = (size_t)16 << 20;                        // 16 Mi rows per call
+static const size_t kStaticScratchDoubles = kStaticCentroidMaxRows / kChunk * kCenW;  // 16384 chunks x 3 sums = 384 KiB
+static __device__ __align__(256) double scratch[kStaticScratchDoubles];
+static const int kMaxDevices = 64;
+static double *g_scratch_ptr[kMaxDevices];   // per device, set once under g_scratch_mu
+static std::mutex g_scratch_mu;
+
+static int static_scratch(int device, double **out)
+{
+    if (device < 0 || device >= kMaxDevices) return fail(ICP_AMD_EINVAL, "device %d: the static scratch serves devices 0..%d", device, kMaxDevices - 1);
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    if (!g_scratch_ptr[device]) {
+        double *p = nullptr;
+        HIPCHK(hipGetSymbolAddress((void **)&p, HIP_SYMBOL(scratch)));   // the current device's copy (require_device set it)
+        if (!p) return fail(ICP_AMD_EHIP, "hipGetSymbolAddress returned a null address for the static scratch");
+        g_scratch_ptr[device] = p;
+    }
+    *out = g_scratch_ptr[device];
+    return ICP_AMD_OK;
+}
+
+extern "C" size_t icp_amd_centroid_static_max_rows(void) { return kStaticCentroidMaxRows; }
+
+extern "C" int icp_amd_centroid_static(const double *A_dev, size_t n, double *out_dev, int device, void *stream)
+{
+    if (!A_dev || !out_dev) return fail(ICP_AMD_EINVAL, "icp_amd_centroid_static: NULL argument");
+    if (n == 0) return fail(ICP_AMD_EINVAL, "icp_amd_centroid_static: empty cloud");
+    if (n > kStaticCentroidMaxRows)
+        return fail(ICP_AMD_EINVAL, "icp_amd_centroid_static: %zu rows exceed the static scratch (limit %zu rows); use icp_amd_centroid",
+                    n, kStaticCentroidMaxRows);
+    RCCHK(require_device(device));
+    double *part = nullptr;
+    RCCHK(static_scratch(device, &part));
+    hipStream_t s = (hipStream_t)stream;
+    const size_t chunks = (n + kChunk - 1) / kChunk;
+    // both kernels overwrite / read exactly `chunks` partials: nothing of an earlier call's contents is read, nothing to clear
+    HIPCHK(colsum_partials(s, A_dev, Soa3{nullptr, nullptr, nullptr}, n, part));
+    HIPCHK(finalize_centroid(s, part, chunks, (double)n, out_dev));
     return ICP_AMD_OK;
 }
 

@@ -201,6 +201,16 @@ int icp_amd_cross_cov(const double *P_xyz, size_t n, const double Pc[3], const d
                       const int32_t *idx, double cov[9]);
 /* mean_0 (include/libgpualg/mean.cuh; src/gpu/icp.cu:537,551) */
 int icp_amd_centroid(const double *A_xyz, size_t n, double out[3]);
+/* icp_amd_centroid for callers that cannot allocate.  NO counterpart in the reference: it exists for code under HIP graph
+ * capture, tight serving loops and harnesses that forbid hipMalloc.  It calls no hipMalloc / hipFree / allocating routine.
+ * A_dev: n x 3 row-major doubles ALREADY in device memory on `device`; out_dev: 3 doubles in device memory; both kernels
+ * are enqueued on `stream` (a hipStream_t; NULL = the null stream) and the call does not synchronise.  The per-chunk partial
+ * sums live in a static device array of the library (384 KiB on every GPU the library runs on, held until the process
+ * ends), which limits n to icp_amd_centroid_static_max_rows() = 16 Mi rows: larger n is ICP_AMD_EINVAL.  Every call on a
+ * GPU shares that GPU's array, so calls that overlap on one GPU (different streams or host threads) race -- serialise them.
+ * Result: bit-identical to icp_amd_centroid on the same rows. */
+int    icp_amd_centroid_static(const double *A_dev, size_t n, double *out_dev, int device, void *stream);
+size_t icp_amd_centroid_static_max_rows(void);
 /* svd_gpu + matrixMultiplication + gpuTranspose + matrix_op (src/gpu/icp.cu:588-611) */
 int icp_amd_solve(const double cov[9], const double Pc[3], const double Qc[3], double R[9], double t[3], double S[3]);
 /* matrixMultiplication(P, R^T) + matrix_op(ADD t) (src/gpu/icp.cu:617-626) */
