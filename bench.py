@@ -375,7 +375,7 @@ def main():
         td.all_reduce(buf, op=td.ReduceOp.SUM)
         return [float(v) for v in buf.cpu()]
 
-    def run(search, steps, warmup, repeats=0, extras=False):
+    def run(search, steps, warmup, repeats=0, extras=False, block_times=False):
         """`steps` timed iterations after `warmup` untimed ones.  Returns a dict: seconds (max over ranks), the search
         kernel's average launch ms (this rank's and every rank's), geometry, the last iteration's outputs, ..."""
         runner = icpdist.ShardedIcp(P, Q, rank=rank, world=world, device=local_rank, search=search, kernel_timing=True)
@@ -395,15 +395,20 @@ def main():
         barrier()
         runner.engine.kernel_ms()             # drop the warm-up launches from the kernel timer
         t0 = time.perf_counter()
-        for _ in range(steps):
+        blocks = []
+        for k in range(steps):
             runner.step()
+            if block_times and (k + 1) % 10 == 0:   # the grid leg: how the step time develops while the clouds converge
+                barrier()
+                blocks.append(time.perf_counter())
         barrier()
         dt = time.perf_counter() - t0
         dt = max(all_ranks(dt))
         avg_ms, _, launches = runner.engine.kernel_ms()
         res = {"dt": dt, "avg_ms": avg_ms, "launches": launches, "geo": runner.engine.search_geometry(),
                "last": runner.engine.get_last(), "n_local": runner.n_local, "grid_stats": runner.engine.grid_stats(),
-               "first_ms": first_ms, "rank_ms": all_ranks(avg_ms)}
+               "first_ms": first_ms, "rank_ms": all_ranks(avg_ms),
+               "ms_per_step_by_10": [round((b - a) * 100.0, 4) for a, b in zip([t0] + blocks[:-1], blocks)]}
         # outside the timed region: a few more steps, each bracketed on its own, for the spread (median + min)
         for _ in range(repeats):
             barrier()
@@ -449,13 +454,24 @@ def main():
         # The same iterations with the grid search (identical results, a fraction of the distance evaluations):
         # reported beside the headline as iterations/s, never as evals/s.
         g_steps = max(args.steps * 10, 50)
-        gr = run("grid", g_steps, max(args.warmup, 3))
+        # two measurements: the first g_steps iterations of a registration (the clouds still move, search boxes are wide,
+        # few rows hold a motion certificate) and g_steps iterations after 3 x g_steps more (the registration has settled:
+        # what a long run spends most of its iterations in)
+        early = run("grid", g_steps, max(args.warmup, 3), block_times=True)
+        gr = run("grid", g_steps, max(args.warmup, 3) + 3 * g_steps, block_times=True)
         g_dt, g_ms, g_geo, g_stats = gr["dt"], gr["avg_ms"], gr["geo"], gr["grid_stats"]
         grid = {"ms_per_step": g_dt / g_steps * 1e3, "iters_per_sec": g_steps / g_dt, "steps": g_steps,
+                "warmup_steps": max(args.warmup, 3) + 3 * g_steps,
                 "speedup_vs_brute_force": (dt / args.steps) / (g_dt / g_steps), "search_kernel_avg_ms": g_ms,
                 "search": g_geo, "stats": g_stats, "first_step_ms": gr["first_ms"],
+                "ms_per_step_by_10": gr["ms_per_step_by_10"],
+                "first_steps": {"ms_per_step": early["dt"] / g_steps * 1e3, "iters_per_sec": g_steps / early["dt"], "steps": g_steps,
+                                "warmup_steps": max(args.warmup, 3), "ms_per_step_by_10": early["ms_per_step_by_10"],
+                                "search_kernel_avg_ms": early["avg_ms"]},
                 "note": "exact nearest neighbour over a uniform grid (icp_amd/csrc/grid.hip): same correspondences as the "
-                        "brute-force search, only the targets near each source point are evaluated; not counted in `value`"}
+                        "brute-force search, only the targets near each source point are evaluated; not counted in `value`. "
+                        "`ms_per_step` is taken once the registration has settled (after `warmup_steps` iterations); "
+                        "`first_steps` is the same measurement at the start of the registration"}
 
     if rank == 0:
         pairs = float(N) * float(M)

@@ -172,6 +172,8 @@ struct icp_amd_engine {
 
     // search
     int variant = kExact, ppl = 4, q_splits = 1, q_splits_first = 1, cb = 8;
+    unsigned updates_since_search = 0;   // step_update calls since the last search (the grid's motion certificate needs exactly 1)
+    bool grid_cert = true;      // ICP_AMD_GRID_CERT=0: every row is searched every iteration (tests)
     bool have_prev = false;     // idx holds the previous iteration's correspondences (search seed)
     bool seed_enabled = true;   // ICP_AMD_SEED=0 switches seeding off (read when the search is planned)
     double *keys = nullptr;
@@ -182,10 +184,11 @@ struct icp_amd_engine {
     // partials
     double *cov_part = nullptr, *cen_part = nullptr;  // world*cpr*{12,3}; own or caller's gather buffers
     bool own_part = false;
-    double *rec = nullptr;      // kSolveW doubles: outputs of the most recent solve; + 3: pairs used, |R - I|, |motion of Pc|
+    double *rec = nullptr;      // kSolveW doubles: outputs of the most recent solve; + 4: pairs used, |R - I|, |motion of Pc|, |R^T R - I|_F
     double reject_d2 = std::numeric_limits<double>::infinity();   // f-4: pairs farther apart get weight 0 (inf = reference)
 
     bool have_target = false, have_source = false, cen_ready = false;
+
 
     // timing of the search launches
     std::vector<hipEvent_t> ev;  // pairs
@@ -231,7 +234,8 @@ extern "C" int icp_amd_create(icp_amd_engine **out, const icp_amd_options *opt_i
     }
     hipError_t er = dmalloc(&e->qc, 3 * sizeof(double));
     if (er == hipSuccess) er = dmalloc(&e->pc, 3 * sizeof(double));
-    if (er == hipSuccess) er = dmalloc(&e->rec, (kSolveW + 3) * sizeof(double));
+    if (er == hipSuccess) er = dmalloc(&e->rec, (kSolveW + 4) * sizeof(double));
+
     if (er != hipSuccess) { icp_amd_destroy(e); return fail(ICP_AMD_ENOMEM, "hipMalloc: %s", hipGetErrorString(er)); }
     *out = e;
     return ICP_AMD_OK;
@@ -343,21 +347,17 @@ static int requested_variant(const icp_amd_engine *e)
     if (sv && !strcmp(sv, "auto")) variant = 0;
     return variant;
 }
-// F32's pre-filter runs on the matrix pipe: by default on the fp16 K = 16 MFMA with every operand in two fp16 pieces
-// (search_mfma.hip; 2.3 times the packed-VALU kernel at 1M x 1M, same results).  ICP_AMD_MFMA=0 selects the packed-VALU
-// kernel, ICP_AMD_MFMA=2|4|8 the fp32 MFMA (measured slower than either: it does not co-execute with the VALU; the value
-// is its number of 32-row source groups per wave), ICP_AMD_MFMA_G the groups of the fp16 kernel.
+// F32's pre-filter runs on the matrix pipe: the fp16 K = 16 MFMA with every operand in two fp16 pieces (search_mfma.hip; 2.5
+// times the packed-VALU kernel at 1M x 1M, same results).  ICP_AMD_MFMA=0 selects the packed-VALU kernel, ICP_AMD_MFMA_G the
+// 32-row source groups per wave of the matrix kernel.
 static int mfma_groups(size_t n_pad)
 {
-    const int v = env_int("ICP_AMD_MFMA", 16);
-    if (v == 16) {
-        // 128 source rows x groups per workgroup: small clouds need the workgroups more than the operand reuse
-        const int g = env_int("ICP_AMD_MFMA_G", n_pad < 120000 ? 2 : 4);
-        return g == 2 ? 2 : 4;   // four waves per SIMD: eight groups would not fit the register file
-    }
-    return (v == 2 || v == 4 || v == 8) ? v : 0;
+    if (env_int("ICP_AMD_MFMA", 16) == 0) return 0;
+    // 128 source rows x groups per workgroup: small clouds need the workgroups more than the operand reuse
+    const int g = env_int("ICP_AMD_MFMA_G", n_pad < 120000 ? 2 : 4);
+    return g == 2 ? 2 : 4;   // four waves per SIMD: eight groups would not fit the register file
 }
-static bool mfma_fp16() { return env_int("ICP_AMD_MFMA", 16) == 16; }
+static bool mfma_fp16() { return env_int("ICP_AMD_MFMA", 16) != 0; }
 
 // AUTO searches on the grid from this many targets on: the grid saves 18 us per iteration at 1000 targets (36 at 2000)
 // and costs about 250 us more to set up (tools/tiny_probe.py), so it pays from roughly 15 iterations on here.
@@ -441,6 +441,7 @@ static int plan_search(icp_amd_engine *e)
     }
     choose_geometry(e);
     e->seed_enabled = env_int("ICP_AMD_SEED", 1) != 0;
+    e->grid_cert = env_int("ICP_AMD_GRID_CERT", 1) != 0;
     // On the grid path the brute-force kernels are only AUTO's fallback: their scratch (12 bytes per source row and
     // target split, 0.4 GB at 1M x 1M) is then allocated by the first fallback launch instead of here.
     if (!e->use_grid) RCCHK(ensure_split_buffers(e));
@@ -627,8 +628,10 @@ extern "C" int icp_amd_step_search(icp_amd_engine *e)
         if (!grid) RCCHK(ensure_split_buffers(e));
         if (grid) ++e->grid_launches; else ++e->bf_launches;
         if (grid)
+            // e->rec describes the motion since the previous search only if exactly one update ran in between
             HIPCHK(search_grid(e->stream, e->P, e->n, e->pc, e->grid, e->Qz, e->m, seed ? e->idx : nullptr,
-                               e->order_ok ? e->order : nullptr, &e->gscratch, e->grid_out));
+                               e->order_ok ? e->order : nullptr, &e->gscratch, e->grid_out,
+                               (seed && e->updates_since_search == 1 && e->grid_cert) ? e->rec : nullptr));
         else if (e->variant == kF32 && e->mfma16) {
             if (!e->qrec16_ok) {   // the fp16 records of this target, on first use
                 if (!e->qrec16) HIPCHK(dmalloc(&e->qrec16, 32 * e->m_pad));
@@ -637,10 +640,7 @@ extern "C" int icp_amd_step_search(icp_amd_engine *e)
             }
             HIPCHK(search_mfma16(e->stream, e->mfma_g, e->P, e->n_pad, e->pc, e->Qz, e->qrec16, e->qmax, e->m, e->m_pad, splits,
                                  seeded ? e->idx : nullptr, e->keys, e->idxs));
-        } else if (e->variant == kF32 && e->mfma_g)
-            HIPCHK(search_mfma(e->stream, e->mfma_g, e->P, e->n_pad, e->pc, e->Qz, e->qrec, e->qmax, e->m, e->m_pad, splits,
-                               seeded ? e->idx : nullptr, e->keys, e->idxs));
-        else if (e->variant == kF32)
+        } else if (e->variant == kF32)
             HIPCHK(search_f32(e->stream, e->ppl, e->cb, e->P, e->n_pad, e->pc, e->Qz, e->qrec, e->qmax, e->m, e->m_pad, splits,
                               seeded ? e->idx : nullptr, e->keys, e->idxs));
         else
@@ -651,6 +651,7 @@ extern "C" int icp_amd_step_search(icp_amd_engine *e)
                          grid && !e->P.rec ? e->grid_out : nullptr, grid && e->P.rec, e->idx, e->reject_d2, cov_slot));
         e->have_prev = true;
     }
+    e->updates_since_search = 0;
     return ICP_AMD_OK;
 }
 
@@ -663,6 +664,7 @@ extern "C" int icp_amd_step_update(icp_amd_engine *e)
                  e->rec + kSolveW));
     double *cen_slot = e->cen_part + (size_t)e->opt.rank * e->cpr * kCenW;
     HIPCHK(apply(e->stream, e->P, e->n, e->rec, e->idx, cen_slot));
+    ++e->updates_since_search;
     return ICP_AMD_OK;
 }
 
@@ -880,6 +882,7 @@ struct Rccl {
     int (*CommInitAll)(comm_t *, int, const int *) = nullptr;
     int (*CommDestroy)(comm_t) = nullptr;
     int (*AllGather)(const void *, void *, size_t, int, comm_t, hipStream_t) = nullptr;
+    int (*Broadcast)(const void *, void *, size_t, int, int, comm_t, hipStream_t) = nullptr;
     int (*GroupStart)() = nullptr;
     int (*GroupEnd)() = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
@@ -895,10 +898,11 @@ struct Rccl {
         CommInitAll = (decltype(CommInitAll))dlsym(handle, "ncclCommInitAll");
         CommDestroy = (decltype(CommDestroy))dlsym(handle, "ncclCommDestroy");
         AllGather = (decltype(AllGather))dlsym(handle, "ncclAllGather");
+        Broadcast = (decltype(Broadcast))dlsym(handle, "ncclBroadcast");
         GroupStart = (decltype(GroupStart))dlsym(handle, "ncclGroupStart");
         GroupEnd = (decltype(GroupEnd))dlsym(handle, "ncclGroupEnd");
         GetErrorString = (decltype(GetErrorString))dlsym(handle, "ncclGetErrorString");
-        return CommInitAll && CommDestroy && AllGather && GroupStart && GroupEnd && GetErrorString;
+        return CommInitAll && CommDestroy && AllGather && Broadcast && GroupStart && GroupEnd && GetErrorString;
     }
 };
 Rccl g_rccl;
@@ -1072,6 +1076,41 @@ extern "C" int icp_amd_run_multi(const double *P, size_t n, const double *Q, siz
                 for (int g = 0; g < G; ++g)
                     if (cnt[g])
                         RCCHK(icp_amd_get_last(r.eng[g], nullptr, tr->idx + (size_t)it * n + lo[g], nullptr, nullptr, nullptr, nullptr, nullptr));
+        }
+    }
+    if (iters && env_int("ICP_AMD_MULTI_CROSSCHECK", 0)) {
+        // Debug cross-check: every device solved R, t redundantly from the same gathered partials, so no
+        // broadcast is needed -- but rank 0's R || t, broadcast (ncclBroadcast, or a peer copy on the RCCL-free exchange),
+        // must then equal every device's own, bit for bit.  A mismatch means the exchange delivered different partials.
+        std::vector<double *> chk(G, nullptr);
+        struct Free { std::vector<double *> &v; std::vector<int> &dev; ~Free() { for (size_t g = 0; g < v.size(); ++g) if (v[g]) { (void)hipSetDevice(dev[g]); (void)dfree(v[g]); } } } fr{chk, r.dev};
+        for (int g = 0; g < G; ++g) {
+            HIPCHK(set_device(r.dev[g]));
+            HIPCHK(dmalloc(&chk[g], 12 * sizeof(double)));
+        }
+        if (r.by_copies) {
+            HIPCHK(set_device(r.dev[0]));
+            HIPCHK(hipStreamSynchronize(r.eng[0]->stream));
+            for (int g = 0; g < G; ++g) {
+                HIPCHK(set_device(r.dev[g]));
+                HIPCHK(hipMemcpyPeerAsync(chk[g], r.dev[g], r.eng[0]->rec + 12, r.dev[0], 12 * sizeof(double), r.eng[g]->stream));
+            }
+        } else {
+            int rc = g_rccl.GroupStart();
+            for (int g = 0; g < G && rc == 0; ++g)
+                rc = g_rccl.Broadcast(r.eng[0]->rec + 12, chk[g], 12, Rccl::kDouble, 0, r.comm[g], r.eng[g]->stream);
+            const int rc2 = g_rccl.GroupEnd();
+            if (rc == 0) rc = rc2;
+            if (rc != 0) return fail(ICP_AMD_EHIP, "RCCL broadcast failed: %s", g_rccl.GetErrorString(rc));
+        }
+        for (int g = 0; g < G; ++g) {
+            double want[12], mine[12];
+            HIPCHK(set_device(r.dev[g]));
+            HIPCHK(hipMemcpyAsync(want, chk[g], sizeof want, hipMemcpyDeviceToHost, r.eng[g]->stream));
+            HIPCHK(hipMemcpyAsync(mine, r.eng[g]->rec + 12, sizeof mine, hipMemcpyDeviceToHost, r.eng[g]->stream));
+            HIPCHK(hipStreamSynchronize(r.eng[g]->stream));
+            if (memcmp(want, mine, sizeof want) != 0)
+                return fail(ICP_AMD_EHIP, "icp_amd_run_multi: cross-check failed, shard %d (device %d) solved a different R, t than shard 0", g, r.dev[g]);
         }
     }
     for (int g = 0; g < G; ++g)
@@ -1373,10 +1412,7 @@ static int correspondences_impl(const double *P, size_t n, const double Pc[3], c
                 HIPCHK(search_mfma16(s, mfma_groups(n_pad), dP, n_pad, pc.as<double>(), dQ, rec16.p, sqrt(qmax2), m, m_pad, q_splits, prev,
                                      keys.as<double>(), idxs.as<uint32_t>()));
                 HIPCHK(hipStreamSynchronize(s));   // rec16 is released on scope exit
-            } else if (mfma_groups(n_pad))
-                HIPCHK(search_mfma(s, mfma_groups(n_pad), dP, n_pad, pc.as<double>(), dQ, qrec.p, sqrt(qmax2), m, m_pad, q_splits, prev,
-                                   keys.as<double>(), idxs.as<uint32_t>()));
-            else
+            } else
                 HIPCHK(search_f32(s, ppl, cb, dP, n_pad, pc.as<double>(), dQ, qrec.p, sqrt(qmax2), m, m_pad, q_splits, prev,
                                   keys.as<double>(), idxs.as<uint32_t>()));
         } else {   // range outside the fp32 bound's domain: same degradation as the engine

@@ -276,6 +276,24 @@ __device__ __forceinline__ void consider_rec(double ax, double ay, double az, co
     }
 }
 
+// Certificate carried from one iteration to the next (grid search with source records): D2 = a lower bound on the computed
+// d^2 of EVERY target other than the matched one, at the row's centred position a of that iteration.  The next iteration
+// moves the row to a' with |a' - a| <= delta (bounded below from the rigid motion the engine applied), so every other
+// target then has a computed d^2 >= (sqrt(D2) - delta)^2 up to a few ulp; if that still clears the tie band of the matched
+// target's new d^2, the match stands -- not even a tie is possible -- and no cell is visited.  Stored as a float rounded
+// DOWN in the upper half of rec[2i+1].w (the lower half is the index); 0 = no certificate.
+__device__ __forceinline__ float float_below(double v)
+{
+    if (!(v > 0.0)) return 0.0f;
+    float f = (float)v;
+    if ((double)f > v) f = __uint_as_float(__float_as_uint(f) - 1u);   // positive: the next float towards zero (inf -> FLT_MAX)
+    return f;
+}
+__device__ __forceinline__ double pack_idx_cert(uint32_t j, float cert)
+{
+    return __longlong_as_double((long long)(((unsigned long long)__float_as_uint(cert) << 32) | (unsigned long long)j));
+}
+
 // One lane per source point.  A lane whose box is large (more than row_cap rows of cells or eval_cap targets -- an
 // outlier far from every target, or an un-seeded first pass) does not walk it alone while the other 63 lanes of its
 // wave wait: it records what it has found so far and queues the point for search_grid_overflow_kernel.
@@ -301,7 +319,8 @@ __global__ __launch_bounds__(kWG) void search_grid_kernel(const double *__restri
                                                           double4 *__restrict__ prec, const uint32_t *__restrict__ order,
                                                           int row_cap, unsigned eval_cap, int defer_always,
                                                           uint32_t *__restrict__ ovf_count,
-                                                          uint32_t *__restrict__ ovf_list, double2 *__restrict__ out_rec)
+                                                          uint32_t *__restrict__ ovf_list, double2 *__restrict__ out_rec,
+                                                          const double *__restrict__ mot)
 {
     const size_t l = (size_t)blockIdx.x * kWG + threadIdx.x;
     if (l >= n) return;
@@ -311,24 +330,30 @@ __global__ __launch_bounds__(kWG) void search_grid_kernel(const double *__restri
     const size_t i = order ? order[l] : l;
     double ax, ay, az, sqx = 0.0, sqy = 0.0, sqz = 0.0;
     uint32_t js = 0xFFFFFFFFu;
+    double cert = 0.0, pl1 = 0.0;   // last iteration's certificate for this row; |p|_1 of the un-centred row
     if (prec) {
         const double4 v0 = prec[2 * i], v1 = prec[2 * i + 1];
         ax = v0.x - pc[0]; ay = v0.y - pc[1]; az = v0.z - pc[2];
         if (idx_prev) js = (uint32_t)__double_as_longlong(v0.w);
         sqx = v1.x; sqy = v1.y; sqz = v1.z;
+        if (idx_prev && mot) {
+            const unsigned long long w1 = (unsigned long long)__double_as_longlong(v1.w);
+            if ((uint32_t)w1 == js) cert = (double)__uint_as_float((uint32_t)(w1 >> 32));   // belongs to this seed
+            pl1 = (__builtin_fabs(v0.x) + __builtin_fabs(v0.y)) + __builtin_fabs(v0.z);
+        }
     } else {
         ax = px[i] - pc[0]; ay = py[i] - pc[1]; az = pz[i] - pc[2];
         if (idx_prev) js = idx_prev[i];
     }
-    double bk = INFINITY, dmin = INFINITY;   // oracle: min_dist = DBL_MAX on the key, idx = -1
+    double dmin = INFINITY;   // oracle: min_dist = DBL_MAX on the key, idx = -1
     uint32_t bj = 0xFFFFFFFFu;
     const double amax = __builtin_fmax(__builtin_fmax(__builtin_fabs(ax), __builtin_fabs(ay)), __builtin_fabs(az));
     if (!(amax < INFINITY) || ax != ax || ay != ay || az != az) {   // every d^2 is inf or NaN: no correspondence
         if (prec) prec[2 * i + 1] = make_double4(0.0, 0.0, 0.0, __longlong_as_double((long long)bj));
-        else out_rec[i] = make_double2(bk, __longlong_as_double((long long)bj));
+        else out_rec[i] = make_double2(INFINITY, __longlong_as_double((long long)bj));
         return;
     }
-    if (!prec && js < m) {   // the coordinates of the seed, for the result record
+    if (!prec && js < m) {   // the coordinates of the seed
         sqx = qrec4 ? qrec4[js].x : qx[js];
         sqy = qrec4 ? qrec4[js].y : qy[js];
         sqz = qrec4 ? qrec4[js].z : qz[js];
@@ -337,16 +362,55 @@ __global__ __launch_bounds__(kWG) void search_grid_kernel(const double *__restri
         const double d = d2_exact(ax, ay, az, sqx, sqy, sqz);
         if (d < INFINITY) {
             dmin = d;
-            bk = key_of(d);
             bj = js;
         }
     }
     double edge = dmin < INFINITY ? tie_band(dmin) : INFINITY;
+    if (cert > 0.0 && bj == js) {
+        // The engine moved every row by p' = fl(R p + t) and re-centred: a' = R a + c + e with c = R Pc + t - Pc' and e the
+        // rounding of the transform and of the two centrings (<= 8u of the magnitudes involved; 2^-48 = 32u is charged).
+        // R is orthogonal up to the defect the solve kernel measured (mot[kSolveW + 3] = |R^T R - I|_F, required < 2^-42), so
+        // a = R^T (a' - c - e) up to 2^-40 (|a'| + |c|), and the row moved by  a' - a = (I - R^T) a' + R^T (c + e):
+        //     |a' - a| <= |(I - R^T) a'| + |c| + eps.
+        // mot = the solve record of that motion: R at [12..20], t at [21..23], the old Pc at [25..27]; pc = the new centroid.
+        const double o0 = mot[25], o1 = mot[26], o2 = mot[27], t0 = mot[21], t1 = mot[22], t2 = mot[23];
+        const double c0 = ((mot[12] * o0 + mot[13] * o1) + mot[14] * o2) + t0 - pc[0];
+        const double c1 = ((mot[15] * o0 + mot[16] * o1) + mot[17] * o2) + t1 - pc[1];
+        const double c2 = ((mot[18] * o0 + mot[19] * o1) + mot[20] * o2) + t2 - pc[2];
+        const double cn = (__builtin_fabs(c0) + __builtin_fabs(c1)) + __builtin_fabs(c2);          // >= |c|_2
+        const double mag = pl1 + ((__builtin_fabs(t0) + __builtin_fabs(t1)) + __builtin_fabs(t2)) +
+                           ((__builtin_fabs(o0) + __builtin_fabs(o1)) + __builtin_fabs(o2)) +
+                           ((__builtin_fabs(pc[0]) + __builtin_fabs(pc[1])) + __builtin_fabs(pc[2]));
+        const double al1 = (__builtin_fabs(ax) + __builtin_fabs(ay)) + __builtin_fabs(az);          // >= |a'|_2
+        // (I - R^T) a': row k of R^T is column k of R
+        const double m0 = ax - ((mot[12] * ax + mot[15] * ay) + mot[18] * az);
+        const double m1 = ay - ((mot[13] * ax + mot[16] * ay) + mot[19] * az);
+        const double m2 = az - ((mot[14] * ax + mot[17] * ay) + mot[20] * az);
+        if (mot[kSolveW + 3] < 0x1p-42) {
+            const double delta = (sqrt((m0 * m0 + m1 * m1) + m2 * m2) + cn) * (1.0 + 0x1p-40) + 0x1p-40 * (al1 + cn) + 0x1p-48 * mag;
+            const double room = sqrt(cert) * (1.0 - 0x1p-40) - delta;
+            const double lower = room > 0.0 ? (room * room) * (1.0 - 0x1p-40) : 0.0;   // every other target's new d^2 is above this
+            if (lower > edge) {
+                prec[2 * i + 1] = make_double4(sqx, sqy, sqz, pack_idx_cert(js, float_below(lower)));
+                return;
+            }
+        }
+    }
     double r = first_radius(g, ax, ay, az, amax, edge);
     unsigned evals = 0;
     bool defer = false;
+    // Keys (two square roots each) are not needed to find the winner of a pass: d1 / d2 = the smallest and the second
+    // smallest d^2 met, k1 = where the smallest sits.  With d2 outside the tie band of d1 that target has the strictly
+    // smallest key; only otherwise (near-ties, duplicated targets, lattices) the box is walked once more, comparing
+    // (key, index) among the targets inside the band -- which are the only ones that can hold the smallest key.
+    double d1 = INFINITY, d2 = INFINITY, Bfinal = 0.0;
+    uint32_t k1 = 0;
+    Box b;
     for (;;) {
-        const Box b = make_box(g, ax, ay, az, r);
+        b = make_box(g, ax, ay, az, r);
+        d1 = INFINITY;     // every pass meets every target of its box exactly once, the seed included
+        d2 = INFINITY;
+        Bfinal = b.all ? INFINITY : b.B;
         if (ovf_list) {
             // A large box is handed over when it would keep this lane busy while most of its wave idles (an outlier);
             // when most lanes of the wave have large boxes (an un-seeded pass over a scan, whose cells are mostly empty)
@@ -359,29 +423,98 @@ __global__ __launch_bounds__(kWG) void search_grid_kernel(const double *__restri
                 break;
             }
         }
-        for (int cz = b.cz0; cz <= b.cz1 && !defer; ++cz) {
-            for (int cy = b.cy0; cy <= b.cy1; ++cy) {
-                // the cells cx0..cx1 of one (cy, cz) row are adjacent in the sorted arrays
-                const size_t row = ((size_t)cz * (size_t)g.dim[1] + (size_t)cy) * (size_t)g.dim[0];
-                const uint32_t k0 = start[row + b.cx0], k1 = start[row + b.cx1 + 1];
-                evals += k1 - k0;
-                if (ovf_list && evals > eval_cap) {
-                    const int n_big = __popcll(__ballot(true));   // lanes of the wave that are past the cap here, roughly
-                    if (defer_always || evals > 16u * eval_cap || 4 * n_big < 64) {
-                        defer = true;
-                        break;
+        // The cells cx0..cx1 of one (cy, cz) row are adjacent in the sorted arrays: a row is one run [k0, k1) of target
+        // records.  Rows are taken four at a time -- their eight cell-start loads go out together -- and the runs of a group
+        // are walked as ONE flattened sequence, four record loads in flight per lane: the wave then iterates max-over-lanes
+        // of (candidates / 4) times instead of once per candidate of the longest run of every row, which is what bounds
+        // this latency-bound kernel.  The visiting order changes nothing.
+        int cy = b.cy0, cz = b.cz0;
+        while (cz <= b.cz1 && !defer) {
+            uint32_t kb[4], ce[4], total = 0;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                uint32_t a0 = 0, a1 = 0;
+                if (cz <= b.cz1) {
+                    const size_t row = ((size_t)cz * (size_t)g.dim[1] + (size_t)cy) * (size_t)g.dim[0];
+                    a0 = start[row + b.cx0];
+                    a1 = start[row + b.cx1 + 1];
+                    if (++cy > b.cy1) { cy = b.cy0; ++cz; }
+                }
+                kb[u] = a0;
+                total += a1 - a0;
+                ce[u] = total;
+            }
+            evals += total;
+            if (ovf_list && evals > eval_cap) {
+                const int n_big = __popcll(__ballot(true));   // lanes of the wave that are past the cap here, roughly
+                if (defer_always || evals > 16u * eval_cap || 4 * n_big < 64) {
+                    defer = true;
+                    break;
+                }
+            }
+            for (uint32_t t = 0; t < total; t += 4) {
+                double4 v[4];
+                uint32_t kk[4];
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    const uint32_t tt = (t + w < total) ? t + w : t;   // past the end: a record that is met anyway
+                    kk[w] = tt < ce[0] ? kb[0] + tt : tt < ce[1] ? kb[1] + (tt - ce[0]) : tt < ce[2] ? kb[2] + (tt - ce[1]) : kb[3] + (tt - ce[2]);
+                    v[w] = rec[kk[w]];
+                }
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    if (w == 0 || t + w < total) {
+                        const double d = d2_exact(ax, ay, az, v[w].x, v[w].y, v[w].z);
+                        d2 = __builtin_fmin(d2, __builtin_fmax(d, d1));
+                        k1 = d < d1 ? kk[w] : k1;
+                        d1 = __builtin_fmin(d1, d);
                     }
                 }
-                for (uint32_t k = k0; k < k1; ++k) consider_rec(ax, ay, az, rec[k], dmin, edge, bk, bj, sqx, sqy, sqz);
             }
         }
-        if (defer || b.all || b.B > edge) break;
+        if (defer) break;
+        if (d1 < INFINITY) {
+            dmin = d1;
+            edge = tie_band(d1);
+        }
+        if (b.all || b.B > edge) break;
         r = next_radius(edge, r);
     }
-    // the result (deferred: the best so far, the overflow kernel starts from it): with source records, the matched target
-    // goes into the second half of this row's own line -- the covariance kernel and the next search read it from there
-    if (prec) prec[2 * i + 1] = make_double4(sqx, sqy, sqz, __longlong_as_double((long long)bj));
-    else out_rec[i] = make_double2(bk, __longlong_as_double((long long)bj));
+    float c = 0.0f;   // the certificate of this search (header of float_below): none for near-ties and deferred rows
+    if (!defer && d1 < INFINITY) {
+        if (d2 > edge) {
+            const double4 v = rec[k1];   // just read: the unique minimum
+            bj = (uint32_t)__double_as_longlong(v.w);
+            sqx = v.x; sqy = v.y; sqz = v.z;
+            if (mot) c = float_below(__builtin_fmin(d2, Bfinal));
+        } else {
+            // near-ties: (key, index) among the targets inside the band, over the same box
+            double bk = INFINITY;
+            bj = 0xFFFFFFFFu;
+            for (int cz = b.cz0; cz <= b.cz1; ++cz)
+                for (int cy = b.cy0; cy <= b.cy1; ++cy) {
+                    const size_t row = ((size_t)cz * (size_t)g.dim[1] + (size_t)cy) * (size_t)g.dim[0];
+                    const uint32_t k0 = start[row + b.cx0], ke = start[row + b.cx1 + 1];
+                    for (uint32_t k = k0; k < ke; ++k) {
+                        const double4 v = rec[k];
+                        const double d = d2_exact(ax, ay, az, v.x, v.y, v.z);
+                        if (d <= edge) {
+                            const double key = key_of(d);
+                            const uint32_t j = (uint32_t)__double_as_longlong(v.w);
+                            if (key < bk || (key == bk && j < bj)) {
+                                bk = key;
+                                bj = j;
+                                sqx = v.x; sqy = v.y; sqz = v.z;
+                            }
+                        }
+                    }
+                }
+        }
+    }
+    // the result (deferred: the seed, the overflow kernel starts from it): with source records, the matched target goes
+    // into the second half of this row's own line -- the covariance kernel and the next search read it from there
+    if (prec) prec[2 * i + 1] = make_double4(sqx, sqy, sqz, pack_idx_cert(bj, c));
+    else out_rec[i] = make_double2(dmin, __longlong_as_double((long long)bj));
     if (defer) ovf_list[atomicAdd(ovf_count, 1u)] = (uint32_t)i;
 }
 
@@ -671,7 +804,7 @@ hipError_t grid_order(hipStream_t s, Soa3 P, size_t n, uint32_t *order)
 }
 
 hipError_t search_grid(hipStream_t s, Soa3 P, size_t n, const double *pc, const Grid &g, Soa3 Qz, size_t m,
-                       const uint32_t *idx_prev, const uint32_t *order, GridScratch *sc, double2 *out_rec)
+                       const uint32_t *idx_prev, const uint32_t *order, GridScratch *sc, double2 *out_rec, const double *motion)
 {
     if (!g.ok || m == 0 || m > 0xFFFFFFF0u) return hipErrorInvalidValue;
     if (n == 0) return hipSuccess;
@@ -680,10 +813,10 @@ hipError_t search_grid(hipStream_t s, Soa3 P, size_t n, const double *pc, const 
     search_grid_kernel<<<(unsigned)((n + kWG - 1) / kWG), kWG, 0, s>>>(P.x, P.y, P.z, pc, n, g.d, g.start, g.rec, Qz.x, Qz.y, Qz.z,
                                                                       Qz.rec, (unsigned)m, idx_prev, P.rec, order, row_cap,
                                                                       (unsigned)eval_cap, sc ? sc->defer_always : 0, cnt,
-                                                                      sc ? sc->list : nullptr, out_rec);
+                                                                      sc ? sc->list : nullptr, out_rec, P.rec ? motion : nullptr);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || !sc) return e;
-    size_t wgs = n < 2048 ? n : 2048;
+    size_t wgs = n < 512 ? n : 512;   // two per CU walk the queue; an empty queue (the usual case) costs the launch only
     search_grid_overflow_kernel<<<(unsigned)wgs, kWG, 0, s>>>(P.x, P.y, P.z, pc, g.d, g.start, g.rec, Qz.x, Qz.y, Qz.z, Qz.rec,
                                                              (unsigned)m, cnt, cnt_next, sc->list, sc->host_count, P.rec, out_rec);
     sc->parity ^= 1;

@@ -68,13 +68,8 @@ hipError_t search_f32(hipStream_t s, int ppl, int cb, Soa3 P, size_t n_pad, cons
                       double qmax, size_t m, size_t m_pad, int q_splits, const uint32_t *idx_prev, double *out_key,
                       uint32_t *out_idx);
 
-// The same pre-filter on the matrix pipe (search_mfma.hip): two v_mfma_f32_32x32x2_f32 per 32 targets x 32 source rows.
-// Same records, same results as search_f32; groups in {2,4,8} = 32-row source groups per wave, a workgroup covers
-// search_mfma_rows_per_workgroup(groups) = 128 * groups source rows.
+// source rows per workgroup of the matrix-pipe filter: 128 * groups (groups = 32-row source groups per wave, 2 or 4)
 int search_mfma_rows_per_workgroup(int groups);
-hipError_t search_mfma(hipStream_t s, int groups, Soa3 P, size_t n_pad, const double *pc, Soa3 Qz, const void *qrec, double qmax,
-                       size_t m, size_t m_pad, int q_splits, const uint32_t *idx_prev, double *out_key, uint32_t *out_idx);
-
 // The filter on v_mfma_f32_32x32x16_f16 (search_mfma.hip): every operand in two fp16 pieces after a power-of-two scaling.
 // rec16: 32 bytes per target (2 * m_pad 16-byte halves) built by build_qrec16 from the centred target and qmax.
 hipError_t build_qrec16(hipStream_t s, Soa3 Qz, size_t m, size_t m_pad, double qmax, void *rec16);
@@ -129,8 +124,13 @@ void grid_scratch_free(GridScratch *sc);
 // when P.rec is not set; with P.rec the result goes into P.rec[2i+1] = {matched target's coordinates, idx}.
 // P.rec, when set, holds TWO records per source row: {x, y, z, previous idx (bit pattern)} and {coordinates of that
 // target, unused} -- everything a lane needs of its row in one 64-byte line (kept current by apply and merge_cov).
+// motion (optional, only used with P.rec and idx_prev): the solve record (kSolveW doubles) of the rigid motion that took the
+// source rows from their position at the previous search to the present one, pc being the centroid of the moved cloud.
+// With it a row whose previous search left a certificate wide enough for that motion keeps its match without visiting a
+// cell (grid.hip); nullptr = every row is searched.
 hipError_t search_grid(hipStream_t s, Soa3 P, size_t n, const double *pc, const Grid &g, Soa3 Qz, size_t m,
-                       const uint32_t *idx_prev, const uint32_t *order, GridScratch *sc, double2 *out_rec);
+                       const uint32_t *idx_prev, const uint32_t *order, GridScratch *sc, double2 *out_rec,
+                       const double *motion = nullptr);
 // P.rec[2i] = {x, y, z, "no index"}, P.rec[2i+1] = 0 for i < rows
 hipError_t build_source_rec(hipStream_t s, Soa3 P, size_t rows);
 hipError_t grid_order(hipStream_t s, Soa3 P, size_t n, uint32_t *order);
@@ -152,7 +152,7 @@ hipError_t cov_from_idx(hipStream_t s, Soa3 P, size_t n, const double *pc, Soa3 
 // Sum `count` cov partials in the same fixed order, 3x3 SVD, R = U V^T, t = Qc - Pc R^T.
 // out: [0..8] cov, [9..11] S, [12..20] R, [21..23] t, [24] rms, [25..27] Pc copy  (28 doubles)
 constexpr int kSolveW = 28;
-// n_global <= 0: rms over the pairs counted in slot 10.  extra (optional, 3 doubles): pairs used, max |R - I|,
+// n_global <= 0: rms over the pairs counted in slot 10.  extra (optional, 4 doubles): pairs used, max |R - I|,
 // max |R Pc + t - Pc| -- how far this iteration's motion is from the identity.
 hipError_t solve(hipStream_t s, const double *partial, size_t count, const double *pc, const double *qc,
                  double n_global, double *out, double *extra);

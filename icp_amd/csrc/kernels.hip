@@ -597,12 +597,14 @@ __device__ void svd3(const double *A, double *U, double *S, double *VT)
 
 __device__ void solve_record(const double *tot, const double *pc, const double *qc, double n_global, double *out);
 
-__global__ __launch_bounds__(kWG) void solve_kernel(const double *__restrict__ partial, size_t count,
-                                                    const double *__restrict__ pc, const double *__restrict__ qc,
-                                                    double n_global, double *__restrict__ out, double *__restrict__ extra)
+__device__ void solve_record(const double *tot, const double *pc, const double *qc, double n_global, double *out);
+
+// One workgroup: the fixed-order sum of all chunk partials, then one lane solves.  Called by solve_kernel and by the last
+// workgroup of cov_kernel (single-GPU engines: the solve rides on the covariance launch).
+__device__ void solve_from_partials(const double *__restrict__ partial, size_t count, const double *__restrict__ pc,
+                                    const double *__restrict__ qc, double n_global, double *__restrict__ out,
+                                    double *__restrict__ extra, double *stage /* 256 * kCovW */, double *tot /* kCovW */)
 {
-    __shared__ double stage[256 * kCovW];
-    __shared__ double tot[kCovW];
     const double acc = ordered_sum<kCovW>(partial, count, stage);
     if (threadIdx.x < kCovW) tot[threadIdx.x] = acc;
     __syncthreads();
@@ -620,7 +622,27 @@ __global__ __launch_bounds__(kWG) void solve_kernel(const double *__restrict__ p
         extra[0] = tot[10];
         extra[1] = dr;
         extra[2] = dt;
+        // |R^T R - I|_F: how far R is from orthogonal (a few ulp; NaN for a NaN covariance) -- the grid search's motion
+        // certificate inverts R by its transpose and asks for < 2^-42
+        double defect = 0.0;
+        for (int a = 0; a < 3; ++a)
+            for (int b = 0; b < 3; ++b) {
+                double g = 0.0;
+                for (int k = 0; k < 3; ++k) g += out[12 + k * 3 + a] * out[12 + k * 3 + b];
+                g -= (a == b) ? 1.0 : 0.0;
+                defect += g * g;
+            }
+        extra[3] = sqrt(defect);
     }
+}
+
+__global__ __launch_bounds__(kWG) void solve_kernel(const double *__restrict__ partial, size_t count,
+                                                    const double *__restrict__ pc, const double *__restrict__ qc,
+                                                    double n_global, double *__restrict__ out, double *__restrict__ extra)
+{
+    __shared__ double stage[256 * kCovW];
+    __shared__ double tot[kCovW];
+    solve_from_partials(partial, count, pc, qc, n_global, out, extra, stage, tot);
 }
 
 // One lane: cov -> SVD -> R, t; writes the 28-double record (layout in kernels.h).

@@ -1,37 +1,11 @@
-// icp_amd/csrc/search_mfma.hip -- the fp32 pre-filter of the brute-force search on the matrix pipe (gfx950).
+// icp_amd/csrc/search_mfma.hip -- the reduced-precision pre-filter of the brute-force search on the matrix pipe (gfx950).
 //
-// Same search, same exact slow path and same records as search_f32_kernel (kernels.hip); only the fast path moves.
-// The filter value
+// Same search, same exact slow path as search_f32_kernel (kernels.hip); only the fast path moves.  The filter value
 //     s(i, j) = |q_j|^2 - 2 p_i.q_j        ( = d^2(p_i, q_j) - |p_i|^2 )
-// is a K = 4 contraction of the target record {-2qx, -2qy, -2qz, |q|^2} with the source record {px, py, pz, 1}:
-// two v_mfma_f32_32x32x2_f32 (exact fp32 products and sums, the same arithmetic as an fmaf chain) give a lane the
-// values of 32 targets for one source point.  The matrix pipe does the 8 flops per pair at its own rate
-// (64 flop/clk/SIMD, the rate of the packed fp32 VALU) and the VALU is left with half a v_min3_f32 per pair and the
-// event checks.
-//
-// MEASURED, and why this kernel is opt-in (ICP_AMD_MFMA=2|4|8) rather than the default: on gfx950 the fp32 MFMA does
-// not overlap with VALU work of other waves on the SIMD (SQ_VALU_MFMA_COEXEC_CYCLES = 0 over the whole kernel;
-// SQ_VALU_MFMA_BUSY_CYCLES = 64 per MFMA), so a 32 x 32 block costs its 128 matrix cycles PLUS the ~42 VALU cycles of
-// its eight v_min3_f32 and the event check: 1M x 1M takes 74.2 ms (G = 2), 74.9 (4), 79.4 (8) against 67.3 ms for the
-// packed-VALU kernel, whose 1.5 v_pk_fma_f32 + 0.5 v_min3_f32 per pair occupy the same fp32 datapath for about as long
-// (profiles/r1_v8_mfma_experiment.txt).  Results are identical (tests/test_gpu_parity.py runs both).
-//
-// Operand layout of v_mfma_f32_32x32x2_f32 (D = A x B + C; A is 32 x 2, B is 2 x 32):
-//     lane l supplies A[l % 32][l / 32] and B[l / 32][l % 32]; D[i][l % 32] for 16 rows i comes back in 16 registers.
-// Rows = targets of a 32-target block, columns = source points: lane (c, h) ends with 16 of the 32 filter values of
-// source column c (which 16 does not matter: the running minimum takes them all), its partner (c, 1-h) with the others.
-// K-step 1 carries (x, y), K-step 2 (z, w): half h = 0 supplies {-2qx | px} then {-2qz | pz}, half 1 {-2qy | py} then
-// {|q|^2 | 1}.  In LDS the tile is therefore kept as two float2 arrays, {x, z}[j] and {y, w}[j]: one conflict-free
-// ds_read_b64 per lane feeds both MFMAs of a block, for all G source groups of the wave.
-//
-// Both lanes of a column keep a full search state (running exact bound, best (key, index)) and take the slow path on
-// their own events; a target with d^2 below a lane's bound trips that lane's check, so each lane's best is the best of
-// a superset of the targets it saw, and the lexicographic minimum of the two lanes is the result.
-//
-// Error bound of the filter (eps = 2^-24): every product term passes two input roundings and at most four
-// accumulations, the |q|^2 term one input rounding and at most four accumulations, in whatever order the pipe adds:
-//     |s_fp32 - s| <= eps (13 |p| |q|max + 7 |q|max^2) =: E,
-// used exactly like E of the VALU filter (event threshold bd (1 + 2^-50) - |p|^2 (1 - 2^-50) + E, rounded up).
+// is a small contraction of a target record with a source record, i.e. matrix-pipe work; the VALU is left with half a
+// v_min3_f32 per pair and the event checks.  (Round 1 also carried the same contraction on the fp32 MFMA,
+// v_mfma_f32_32x32x2_f32: it does not co-execute with VALU work on gfx950 and ran at 74 ms against 67 ms for the packed-VALU
+// filter and 28 ms for the fp16 form below -- profiles/r1_v8_mfma_experiment.txt -- so it was removed in round 2.)
 #include "kernels.h"
 #include "search_common.h"
 
@@ -42,121 +16,8 @@ namespace icpk {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int kTileQM = 2048;   // targets per LDS tile (2 x 16 KB)
-constexpr int kRowsM = 32;      // targets per MFMA block = event-check granularity
-
-template <int G>
-__global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(2))) void search_mfma_kernel(const double *__restrict__ px, const double *__restrict__ py,
-                                                          const double *__restrict__ pz, const double *__restrict__ pc,
-                                                          const double *__restrict__ qx, const double *__restrict__ qy,
-                                                          const double *__restrict__ qz, const float4 *__restrict__ qrec,
-                                                          double qmax, unsigned n_pad, unsigned m, unsigned m_scan,
-                                                          unsigned q_per_split, const uint32_t *__restrict__ idx_prev,
-                                                          double *__restrict__ out_key, uint32_t *__restrict__ out_idx)
-{
-    __shared__ float2 sxz[kTileQM], syw[kTileQM];
-    const unsigned tid = threadIdx.x;
-    const unsigned lane = tid & 63u, wave = tid >> 6;
-    const unsigned col = lane & 31u, half = lane >> 5;
-    // source rows of this lane: base + g * 32, g < G (both halves of a column own the same rows)
-    const unsigned base = blockIdx.x * (4u * 32u * G) + wave * (32u * G) + col;
-    const double c0 = pc[0], c1 = pc[1], c2 = pc[2];
-    const unsigned q0 = blockIdx.y * q_per_split;
-    const unsigned q1 = (q0 + q_per_split < m_scan) ? (q0 + q_per_split) : m_scan;
-
-    float b0[G], b1[G], ms[G], thr[G];
-    double bd[G], bk[G];
-    uint32_t bj[G], sblk[G];
-#pragma unroll
-    for (int g = 0; g < G; ++g) {
-        const unsigned row = base + g * 32u;
-        const double ax = px[row] - c0, ay = py[row] - c1, az = pz[row] - c2;
-        const double pn = (ax * ax + ay * ay) + az * az;
-        const double E = 0x1p-24 * (13.0 * sqrt(pn) * qmax + 7.0 * qmax * qmax) + 1e-35;
-        const bool usable = pn < 1e30;   // else: the lane takes the exact path on every block (s = |q|^2 < inf below)
-        const double off = usable ? (E - pn) + pn * 0x1p-50 : INFINITY;
-        b0[g] = usable ? (half ? (float)ay : (float)ax) : 0.0f;
-        b1[g] = half ? 1.0f : (usable ? (float)az : 0.0f);
-        const uint32_t js = idx_prev ? idx_prev[row] : 0xFFFFFFFFu;
-        bd[g] = seed_init<kRowsM>(ax, ay, az, qx, qy, qz, js, m, q0, q1, bk[g], bj[g], sblk[g]);
-        thr[g] = f32_above(__builtin_fma(bd[g], 1.0 + 0x1p-50, off));
-        ms[g] = thr[g];
-    }
-    const float2 *sa = half ? syw : sxz;
-
-    for (unsigned t0 = q0; t0 < q1; t0 += kTileQM) {
-        const int cnt = (q1 - t0 < (unsigned)kTileQM) ? (int)(q1 - t0) : kTileQM;   // multiple of kSplitGran
-        __syncthreads();
-        // global records are pair-interleaved ({a.x,b.x,a.y,b.y}, {a.z,b.z,a.w,b.w} for targets a = 2k, b = 2k+1)
-        for (int k = tid; k < cnt / 2; k += kWG) {
-            const float4 r0 = qrec[(size_t)(t0 / 2 + k) * 2], r1 = qrec[(size_t)(t0 / 2 + k) * 2 + 1];
-            ((float4 *)sxz)[k] = make_float4(r0.x, r1.x, r0.y, r1.y);
-            ((float4 *)syw)[k] = make_float4(r0.z, r1.z, r0.w, r1.w);
-        }
-        __syncthreads();
-        for (int j0 = 0; j0 < cnt; j0 += kRowsM) {
-            const float2 a = sa[j0 + col];
-            f32x16 acc[G];
-#pragma unroll
-            for (int g = 0; g < G; ++g) {
-                const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-                acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b0[g], zero, 0, 0, 0);
-            }
-#pragma unroll
-            for (int g = 0; g < G; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b1[g], acc[g], 0, 0, 0);
-#pragma unroll
-            for (int g = 0; g < G; ++g) {
-                float v = ms[g];
-#pragma unroll
-                for (int r = 0; r < 16; r += 2) v = vmin3f(v, acc[g][r], acc[g][r + 1]);
-                ms[g] = v;
-            }
-            const unsigned blk = (t0 + (unsigned)j0) / kRowsM;
-            bool ev = false;
-#pragma unroll
-            for (int g = 0; g < G; ++g) {
-                if (blk == sblk[g]) ms[g] = thr[g];   // the seed's own block was evaluated exactly by seed_init
-                ev |= (ms[g] < thr[g]);
-            }
-            if (ev) {
-#pragma unroll
-                for (int g = 0; g < G; ++g) {
-                    if (ms[g] < thr[g]) {
-                        // exact re-evaluation of the block in fp64 from the source arrays (rare: reloaded, not kept in registers)
-                        const unsigned row = base + g * 32u;
-                        const double ax = px[row] - c0, ay = py[row] - c1, az = pz[row] - c2;
-                        const double pn = (ax * ax + ay * ay) + az * az;
-                        const double E = 0x1p-24 * (13.0 * sqrt(pn) * qmax + 7.0 * qmax * qmax) + 1e-35;
-                        const double off = (pn < 1e30) ? (E - pn) + pn * 0x1p-50 : INFINITY;
-                        const unsigned jg = t0 + (unsigned)j0;
-                        double dbest;
-                        rescan_block<kRowsM>(ax, ay, az, qx + jg, qy + jg, qz + jg, 0, jg, bd[g], bk[g], bj[g], dbest);
-                        thr[g] = f32_above(__builtin_fma(bd[g], 1.0 + 0x1p-50, off));
-                        ms[g] = thr[g];
-                    }
-                }
-            }
-        }
-    }
-    // the two lanes of a column hold two valid partial results: the lexicographic minimum is the split's record
-    const size_t o = (size_t)blockIdx.y * n_pad + base;
-#pragma unroll
-    for (int g = 0; g < G; ++g) {
-        const double ok = __shfl_xor(bk[g], 32, 64);
-        const uint32_t oj = __shfl_xor(bj[g], 32, 64);
-        if (ok < bk[g] || (ok == bk[g] && oj < bj[g])) {
-            bk[g] = ok;
-            bj[g] = oj;
-        }
-        if (half == 0) {
-            out_key[o + g * 32u] = bk[g];
-            out_idx[o + g * 32u] = bj[g];
-        }
-    }
-}
-
 // ------------------------------------------------------------------------------------------------
-// the same filter on v_mfma_f32_32x32x16_f16: one MFMA per 32 targets x 32 source rows
+// the filter on v_mfma_f32_32x32x16_f16: one MFMA per 32 targets x 32 source rows
 // ------------------------------------------------------------------------------------------------
 // The K = 16 half-precision MFMA of gfx950 runs at 16 times the fp32 matrix rate, and K = 16 is room to carry every
 // operand in TWO fp16 pieces (hi + lo, 22 bits) -- after scaling both clouds by a power of two sigma that puts the largest
@@ -548,24 +409,5 @@ hipError_t search_mfma16(hipStream_t s, int groups, Soa3 P, size_t n_pad, const 
 }
 
 int search_mfma_rows_per_workgroup(int groups) { return 128 * groups; }
-
-hipError_t search_mfma(hipStream_t s, int groups, Soa3 P, size_t n_pad, const double *pc, Soa3 Qz, const void *qrec, double qmax,
-                       size_t m, size_t m_pad, int q_splits, const uint32_t *idx_prev, double *out_key, uint32_t *out_idx)
-{
-    if (n_pad == 0 || m_pad == 0 || n_pad % 2048 || m_pad % kTileQM || q_splits < 1 || m > m_pad || !(qmax >= 0.0))
-        return hipErrorInvalidValue;
-    const unsigned m_scan = (unsigned)search_scan_rows(m);
-    const unsigned q_per_split = (unsigned)search_rows_per_split(m, q_splits);
-#define ICPK_CASE(G_) \
-    if (groups == G_) { \
-        dim3 grid((unsigned)(n_pad / (128 * G_)), (unsigned)q_splits); \
-        search_mfma_kernel<G_><<<grid, kWG, 0, s>>>(P.x, P.y, P.z, pc, Qz.x, Qz.y, Qz.z, (const float4 *)qrec, qmax, (unsigned)n_pad, \
-                                                  (unsigned)m, m_scan, q_per_split, idx_prev, out_key, out_idx); \
-        return hipGetLastError(); \
-    }
-    ICPK_CASE(2) ICPK_CASE(4) ICPK_CASE(8)
-#undef ICPK_CASE
-    return hipErrorInvalidValue;
-}
 
 }  // namespace icpk

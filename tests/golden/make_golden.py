@@ -100,6 +100,49 @@ def run_icp_case(name, P, Q, iters, keep_p=None, pfile=None, qfile=None, store_i
     print("%-14s N=%d M=%d iters=%d  -> %s.npz" % (name, len(P), len(Q), iters, name))
 
 
+CKPT = os.environ.get("GOLDEN_CKPT", "/tmp/golden_ckpt")
+
+
+def run_icp_case_resumable(name, P, Q, iters, keep_p, inputs_from):
+    """run_icp_case for the long runs (half an hour of reference time): one ref_trace process per iteration, each started
+    from the cloud the previous one wrote (a %.17g CSV round trip is exact, and the reference re-centres the same Q every
+    time, so the chain equals one long run bit for bit), with every iteration's outputs kept under $GOLDEN_CKPT so that an
+    interrupted generation picks up where it stopped."""
+    os.makedirs(CKPT, exist_ok=True)
+    keys = ("Pc", "idx", "cov", "S", "U", "VT", "R", "t")
+    acc = {k: [] for k in keys}
+    p_in = []
+    cur, qc = P, None
+    with tempfile.TemporaryDirectory() as td:
+        qfile = os.path.join(td, "Q.csv")
+        write_csv(qfile, Q)
+        for it in range(iters):
+            ck = os.path.join(CKPT, "%s_it%02d.npz" % (name, it))
+            if os.path.exists(ck):
+                with np.load(ck) as z:
+                    tr = {k: z[k] for k in z.files}
+            else:
+                pfile, out = os.path.join(td, "P.csv"), os.path.join(td, "trace.bin")
+                write_csv(pfile, cur)
+                subprocess.check_call([TRACE, pfile, qfile, "1", out, "1"])
+                tr = read_trace(out)
+                assert np.array_equal(tr["P_in"][0], cur), (name, it)
+                tr = {k: (tr[k][0] if k in keys else tr[k]) for k in list(keys) + ["Qc", "P_out"]}
+                np.savez(ck + ".tmp.npz", **tr)
+                os.replace(ck + ".tmp.npz", ck)
+                print("%-14s iteration %d done" % (name, it), flush=True)
+            if it in keep_p and it > 0:
+                p_in.append(cur)
+            for k in keys:
+                acc[k].append(tr[k])
+            qc, cur = tr["Qc"], tr["P_out"]
+    res = {k: np.stack(acc[k]) for k in keys}
+    res.update(Qc=qc, P_out=cur, P_in=np.stack(p_in), P_in_iters=np.array([k for k in keep_p if k < iters], dtype=np.int32),
+               inputs_from=np.array(inputs_from))
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), iters=np.int32(iters), **res)
+    print("%-14s N=%d M=%d iters=%d  -> %s.npz" % (name, len(P), len(Q), iters, name))
+
+
 def ties_clouds():
     """Adversarial correspondence-only case (SURVEY.md 7.3 hard parts 1-2): inputs are used as-is
     (already 'centred'), so exact and few-ulp ties survive."""
@@ -202,13 +245,13 @@ def bun045_000():
 @case
 def horse_tr1_x20():
     pf, qf = REF + "/icp/horse_tr1.txt", REF + "/icp/horse_ref.txt"
-    run_icp_case("horse_tr1_x20", load_csv(pf), load_csv(qf), 20, keep_p=[0, 1, 10, 19], pfile=pf, qfile=qf, store_inputs=False)
+    run_icp_case_resumable("horse_tr1_x20", load_csv(pf), load_csv(qf), 20, [0, 1, 10, 19], "horse_tr1")
 
 
 @case
 def bun045_000_x20():
     pf, qf = REF + "/icp/bun045.txt", REF + "/icp/bun000.txt"
-    run_icp_case("bun045_000_x20", load_csv(pf), load_csv(qf), 20, keep_p=[0, 1, 10, 19], pfile=pf, qfile=qf, store_inputs=False)
+    run_icp_case_resumable("bun045_000_x20", load_csv(pf), load_csv(qf), 20, [0, 1, 10, 19], "bun045_000")
 
 
 @case
@@ -258,7 +301,26 @@ def run_rows_case(name, n, iters_at, n_rows, threads):
     from oracle import pyoracle as orc
     P, Q = synth.make_pair(n, n)
     last = max(iters_at)
-    tr = orc.icp(P, Q, last, trace=True, trace_p=True, nthreads=threads) if last > 0 else None
+    # the oracle port's trajectory, one iteration per call with a checkpoint each (an iteration at 1M x 1M is minutes):
+    # the chain of one-iteration calls is the loop itself (each starts from the previous call's P_out, Q is re-centred alike)
+    os.makedirs(CKPT, exist_ok=True)
+    tr = {"P_in": [], "idx": []}
+    cur = P
+    for it in range(last):
+        ck = os.path.join(CKPT, "%s_port_it%02d.npz" % (name, it))
+        if os.path.exists(ck):
+            with np.load(ck) as z:
+                one = {k: z[k] for k in z.files}
+        else:
+            r1 = orc.icp(cur, Q, 1, trace=True, nthreads=threads)
+            one = {"idx": r1["idx"][0], "P_out": r1["P_out"]}
+            np.savez(ck + ".tmp.npz", **one)
+            os.replace(ck + ".tmp.npz", ck)
+            print("%-14s oracle-port iteration %d done" % (name, it), flush=True)
+        tr["P_in"].append(cur)
+        tr["idx"].append(one["idx"])
+        cur = one["P_out"]
+    tr["P_out"] = cur
     Qc = orc.mean0(Q)
     Qz = orc.sub_row(Q, Qc)
     rows = np.sort(np.random.RandomState(n % 1000003).choice(n, n_rows, replace=False)).astype(np.int64)

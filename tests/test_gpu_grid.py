@@ -247,3 +247,67 @@ def test_grid_on_surfaces_refines_its_cells_and_keeps_the_results(monkeypatch):
         e.close()
     for o in outs[1:]:
         assert np.array_equal(outs[0][0], o[0]) and np.array_equal(outs[0][1], o[1])
+
+
+def test_motion_certificate_changes_nothing(monkeypatch):
+    """From the second grid iteration on a row keeps its match without visiting a cell when last iteration's search left a
+    certificate (every other target at least D2 away) that is wider than the motion since (grid.hip).  It is only a
+    shortcut: with it (default), without it (ICP_AMD_GRID_CERT=0) and through the brute-force search every iteration gives
+    the same indices and, bit for bit, the same cloud -- on converging pairs (motion shrinks: almost every row skips), on a
+    pair that starts far off (large motion: certificates fail), on tie lattices and duplicated targets (no certificate is
+    ever issued) and across scales / offsets (the bound's rounding terms)."""
+    rng = np.random.RandomState(5)
+    cases = []
+    P, Q = synth.make_pair(40000, 42000, seed=31)
+    cases.append(("converging", P, Q, 14))
+    P2, Q2 = synth.make_pair(20000, 20000, seed=32, angle=0.6, t0=(0.4, -0.3, 0.2))
+    cases.append(("far", P2, Q2, 12))
+    g = golden("lattice")
+    cases.append(("lattice", g["P"], g["Q"], 8))
+    Qd = np.concatenate([Q[:5000], Q[:5000][::-1], Q[5000:9000]])      # every one of the first 5000 targets twice
+    cases.append(("duplicates", P[:6000], Qd, 8))
+    for scale, shift in ((1e-4, 0.0), (1e5, 0.0), (1.0, 3e3), (1e-2, -40.0)):
+        cases.append(("scaled %g %g" % (scale, shift), P[:15000] * scale + shift, Q[:16000] * scale + shift, 8))
+    sheet = rng.uniform(-1, 1, (30000, 3)) * np.array([1.0, 1.0, 1e-3])
+    cases.append(("sheet", sheet[:25000] @ synth.rotation(0.05).T + 0.01, sheet, 10))
+    for name, Pc_, Qc_, iters in cases:
+        runs = {}
+        for label, search, cert in (("cert", "grid", "1"), ("nocert", "grid", "0"), ("brute", "f32", "1")):
+            monkeypatch.setenv("ICP_AMD_GRID_CERT", cert)
+            e = icp_amd.Engine(search=search)
+            e.set_target(Qc_)
+            e.set_source(Pc_)
+            out = []
+            for _ in range(iters):
+                e.iterate(1)
+                out.append(e.get_last()["idx"].copy())
+            runs[label] = (out, e.get_source())
+            e.close()
+        monkeypatch.delenv("ICP_AMD_GRID_CERT")
+        for other in ("nocert", "brute"):
+            for it in range(iters):
+                assert np.array_equal(runs["cert"][0][it], runs[other][0][it]), (name, other, it)
+            assert np.array_equal(runs["cert"][1], runs[other][1]), (name, other)
+
+
+def test_motion_certificate_is_void_after_two_updates_without_a_search():
+    """The certificate describes ONE rigid motion; a caller that applies two updates between searches (step_update twice)
+    must get a full search, not a shortcut priced for half the motion."""
+    P, Q = synth.make_pair(30000, 30000, seed=33, angle=0.3)
+    a = icp_amd.Engine(search="grid")
+    b = icp_amd.Engine(search="f32")
+    for e in (a, b):
+        e.set_target(Q)
+        e.set_source(P)
+        e.step_begin()
+        for _ in range(3):
+            e.step_search()
+            e.step_update()
+        e.step_update()          # the same R, t applied once more, no search in between
+        e.step_search()
+        e.step_update()
+        e.sync()
+    assert np.array_equal(a.get_last()["idx"], b.get_last()["idx"])
+    assert np.array_equal(a.get_source(), b.get_source())
+    a.close()
+    b.close()

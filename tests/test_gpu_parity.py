@@ -122,14 +122,15 @@ def test_fp16_matrix_filter_stays_inside_its_error_bound():
     assert worst_seen < 0.5, worst_seen
 
 
-@pytest.mark.parametrize("groups", ["0", "2", "4", "8", "16"])
-def test_matrix_pipe_prefilter_is_only_a_filter(monkeypatch, groups):
-    """Every implementation of the F32 pre-filter: ICP_AMD_MFMA=16 (the default: v_mfma_f32_32x32x16_f16 on operands in two
-    fp16 pieces), 0 (packed fp32 VALU), 2|4|8 (v_mfma_f32_32x32x2_f32 with that many source groups).  Same indices as the
-    oracle on the golden cases (whole loop, seeded iterations included), on the adversarial ties (stage level, several
-    splits) and across scales / offsets, where its looser error bound only means more slow-path visits."""
+@pytest.mark.parametrize("pipe,groups", [("0", "4"), ("16", "2"), ("16", "4")])
+def test_matrix_pipe_prefilter_is_only_a_filter(monkeypatch, pipe, groups):
+    """Both implementations of the F32 pre-filter: ICP_AMD_MFMA=16 (the default: v_mfma_f32_32x32x16_f16 on operands in two
+    fp16 pieces, with 2 or 4 source groups per wave) and 0 (packed fp32 VALU).  Same indices as the oracle on the golden
+    cases (whole loop, seeded iterations included), on the adversarial ties (stage level, several splits) and across
+    scales / offsets, where its looser error bound only means more slow-path visits."""
     monkeypatch.setenv("ICP_AMD_SEARCH", "f32")
-    monkeypatch.setenv("ICP_AMD_MFMA", groups)
+    monkeypatch.setenv("ICP_AMD_MFMA", pipe)
+    monkeypatch.setenv("ICP_AMD_MFMA_G", groups)
     for name in ("cow_tr1", "syn3k_4k", "lattice", "c1_30pts"):
         g = golden(name)
         P_out, tr = icp_amd.icp_gpu_optimized(g["P"], g["Q"], int(g["iters"]), trace=True)

@@ -141,6 +141,17 @@ def test_bench_two_ranks_on_one_gpu_over_gloo():
     assert d1["rms_last"] == d["rms_last"]
 
 
+def test_native_multi_cross_check_of_the_redundant_solves(monkeypatch):
+    """ICP_AMD_MULTI_CROSSCHECK=1 (SURVEY 8e's debug aid for the first real multi-GPU run): shard 0's R || t is broadcast
+    (ncclBroadcast on a one-rank communicator here; peer copies on a device list that repeats device 0) and compared bit for
+    bit with every shard's own redundant solve.  Results are unchanged and the check passes."""
+    monkeypatch.setenv("ICP_AMD_MULTI_CROSSCHECK", "1")
+    P, Q = synth.make_pair(9000, 8000, seed=47)
+    want = icp_amd.icp_gpu_optimized(P, Q, 4)
+    assert np.array_equal(icp_amd.icp_gpu_multi(P, Q, 4, 1, devices=[0]), want)            # RCCL, one rank
+    assert np.array_equal(icp_amd.icp_gpu_multi(P, Q, 4, 3, devices=[0, 0, 0]), want)      # peer-copy exchange, three shards
+
+
 def test_native_rccl_multi_entry_point():
     """icp_amd_run_multi (single process, RCCL loaded at run time).  On this one-GPU box: a one-rank RCCL communicator
     on an explicit device list exercises the load / init / in-place all-gather / teardown path, and must equal icp_amd_run;

@@ -26,7 +26,7 @@ def run(n, m, iters, env):
     return json.loads(r.stdout.strip().splitlines()[-1])
 sizes = [(int(a), int(b), int(c)) for a, b, c in (s.split("x") for s in sys.argv[1:])] or [(1000000, 1000000, 5), (125952, 1000000, 20), (100000, 100000, 50), (20000, 20000, 100)]
 for n, m, it in sizes:
-    for label, env in (("valu", {"ICP_AMD_MFMA": "0"}), ("mfma4", {"ICP_AMD_MFMA": "4"}),
+    for label, env in (("valu", {"ICP_AMD_MFMA": "0"}),
                        ("h16 g2", {"ICP_AMD_MFMA": "16", "ICP_AMD_MFMA_G": "2"}), ("h16 g4", {"ICP_AMD_MFMA": "16", "ICP_AMD_MFMA_G": "4"})
                        ):
         d = run(n, m, it, env)
