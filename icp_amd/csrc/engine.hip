@@ -159,6 +159,7 @@ struct icp_amd_engine {
     bool grid_auto = false;     // the grid was chosen by AUTO: fall back to brute force while most points overflow
     unsigned bf_left = 0, bf_backoff = 0;   // AUTO: brute-force iterations left before the grid is tried again
     unsigned grid_launches = 0, bf_launches = 0;
+    unsigned grid_since_source = 0;   // grid searches since the source cloud was set (overflow-kernel policy)
 
     // source (local rows)
     size_t n = 0, n_pad = 0, n_global = 0;
@@ -534,6 +535,8 @@ extern "C" int icp_amd_set_source(icp_amd_engine *e, const double *P, size_t n)
     e->have_source = true;
     e->have_prev = false;
     e->cen_ready = false;
+    e->grid_since_source = 0;
+    e->updates_since_search = 0;
     return ICP_AMD_OK;
 }
 
@@ -616,6 +619,7 @@ extern "C" int icp_amd_step_search(icp_amd_engine *e)
             if (e->grid.ok) {
                 if (!e->gscratch.list) HIPCHK(grid_scratch_alloc(e->stream, e->n_pad, &e->gscratch));
                 if (!e->grid_out) HIPCHK(dmalloc(&e->grid_out, e->n_pad * sizeof(double2)));
+                e->gscratch.enabled = true;
                 HIPCHK(search_grid(e->stream, e->P, e->n, e->pc, e->grid, e->Qz, e->m, nullptr, nullptr, &e->gscratch, e->grid_out));
                 // idx <- the grid's correspondences (the partial sums this also writes are overwritten below)
                 HIPCHK(merge_cov(e->stream, e->P, e->n, e->n_pad, e->pc, e->Qz, e->m, 1, nullptr, nullptr, e->grid_out, false, e->idx,
@@ -627,12 +631,19 @@ extern "C" int icp_amd_step_search(icp_amd_engine *e)
         const int splits = grid ? 1 : (seeded ? e->q_splits : e->q_splits_first);
         if (!grid) RCCHK(ensure_split_buffers(e));
         if (grid) ++e->grid_launches; else ++e->bf_launches;
-        if (grid)
+        if (grid) {
+            // The overflow kernel (4 us when its queue is empty, which is the rule once a registration is under way) is
+            // launched for the first grid searches of a source cloud, while the last queue length seen is not zero (a mapped
+            // host word, read without waiting: possibly an iteration old), and every 16th search to refresh that word.
+            // Without it a lane finishes even a large box by itself -- slower for an outlier, never wrong.
+            e->gscratch.enabled = e->gscratch.defer_always || e->grid_since_source < 4 || *e->gscratch.host_mem > 0 ||
+                                  e->grid_since_source % 16 == 0;
+            ++e->grid_since_source;
             // e->rec describes the motion since the previous search only if exactly one update ran in between
             HIPCHK(search_grid(e->stream, e->P, e->n, e->pc, e->grid, e->Qz, e->m, seed ? e->idx : nullptr,
                                e->order_ok ? e->order : nullptr, &e->gscratch, e->grid_out,
                                (seed && e->updates_since_search == 1 && e->grid_cert) ? e->rec : nullptr));
-        else if (e->variant == kF32 && e->mfma16) {
+        } else if (e->variant == kF32 && e->mfma16) {
             if (!e->qrec16_ok) {   // the fp16 records of this target, on first use
                 if (!e->qrec16) HIPCHK(dmalloc(&e->qrec16, 32 * e->m_pad));
                 HIPCHK(build_qrec16(e->stream, e->Qz, e->m, e->m_pad, e->qmax, e->qrec16));

@@ -808,6 +808,7 @@ hipError_t search_grid(hipStream_t s, Soa3 P, size_t n, const double *pc, const 
 {
     if (!g.ok || m == 0 || m > 0xFFFFFFF0u) return hipErrorInvalidValue;
     if (n == 0) return hipSuccess;
+    if (sc && !sc->enabled) sc = nullptr;
     const int row_cap = sc ? sc->row_cap : 64, eval_cap = sc ? sc->eval_cap : 768;
     uint32_t *cnt = sc ? sc->count2 + sc->parity : nullptr, *cnt_next = sc ? sc->count2 + (sc->parity ^ 1) : nullptr;
     search_grid_kernel<<<(unsigned)((n + kWG - 1) / kWG), kWG, 0, s>>>(P.x, P.y, P.z, pc, n, g.d, g.start, g.rec, Qz.x, Qz.y, Qz.z,

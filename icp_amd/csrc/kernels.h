@@ -115,6 +115,8 @@ struct GridScratch {
     int parity = 0;
     int row_cap = 64, eval_cap = 768;       // rows of cells / targets one lane walks alone (read from the environment at allocation)
     int defer_always = 0;                   // 1: hand over every box above the caps (tests); 0: only when most of the wave would idle
+    bool enabled = true;                    // false: this launch hands nothing over (every lane finishes its own point) and the
+                                            // overflow kernel is not launched -- the caller's choice while the queue stays empty
 };
 hipError_t grid_scratch_alloc(hipStream_t s, size_t n, GridScratch *sc);   // s: the stream the searches will run on
 void grid_scratch_free(GridScratch *sc);

@@ -687,18 +687,30 @@ __global__ __launch_bounds__(kWG) void apply_kernel(double *__restrict__ px, dou
     const double t0 = t[0], t1 = t[1], t2 = t[2];
     double acc[3] = {0.0, 0.0, 0.0};
     const size_t base = (size_t)blockIdx.x * kChunk + threadIdx.x;
+    // every load of the workgroup's four row groups goes out before the first dependent use (HBM bound: bytes in flight)
+    double lx[kChunk / kWG], ly[kChunk / kWG], lz[kChunk / kWG];
+    uint32_t lj[kChunk / kWG];
+#pragma unroll
+    for (int k = 0; k < kChunk / kWG; ++k) {
+        const size_t i = base + (size_t)k * kWG;
+        const bool in = i < n;
+        lx[k] = in ? px[i] : 0.0;
+        ly[k] = in ? py[i] : 0.0;
+        lz[k] = in ? pz[i] : 0.0;
+        lj[k] = (in && prec) ? idx[i] : 0u;
+    }
 #pragma unroll
     for (int k = 0; k < kChunk / kWG; ++k) {
         const size_t i = base + (size_t)k * kWG;
         if (i < n) {
-            const double x = px[i], y = py[i], z = pz[i];
+            const double x = lx[k], y = ly[k], z = lz[k];
             const double nx = ((x * r00 + y * r01) + z * r02) + t0;
             const double ny = ((x * r10 + y * r11) + z * r12) + t1;
             const double nz = ((x * r20 + y * r21) + z * r22) + t2;
             px[i] = nx;
             py[i] = ny;
             pz[i] = nz;
-            if (prec) prec[2 * i] = make_double4(nx, ny, nz, __longlong_as_double((long long)idx[i]));
+            if (prec) prec[2 * i] = make_double4(nx, ny, nz, __longlong_as_double((long long)lj[k]));
             acc[0] += nx;
             acc[1] += ny;
             acc[2] += nz;

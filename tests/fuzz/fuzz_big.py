@@ -16,7 +16,7 @@ while time.time() < t_end:
     if time.time() > t_say:
         print("... %d cases, %d mismatches so far" % (cases, bad), flush=True)
         t_say = time.time() + 30
-    n, m, iters = int(rng.randint(1000, 300000)), int(rng.randint(1000, 300000)), int(rng.randint(2, 6))
+    n, m, iters = int(rng.randint(1000, 300000)), int(rng.randint(1000, 300000)), int(rng.randint(2, 13))
     kind = rng.randint(4)
     if kind == 0:
         Q = rng.uniform(-1, 1, (m, 3))

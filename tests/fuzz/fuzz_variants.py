@@ -47,6 +47,9 @@ while time.time() < t_end:
     Pc = orc.mean0(P)
     Qz = Q - orc.mean0(Q)
     want = orc.correspondences(P - Pc, Qz, nthreads=8)
+    # half the cases run the brute-force launches truly un-seeded (the cooperative exact path of the matrix filter), the
+    # other half seeded from the grid's answer like the engine's first iteration
+    os.environ["ICP_AMD_GRID_SEED"] = "0" if rng.rand() < 0.5 else "1"
     for search, splits in (("exact", 1), ("fma", int(rng.randint(1, 9))), ("f32", int(rng.randint(1, 9))), ("grid", 1)):
         got = icp_amd.correspondences(P, Pc, Qz, search=search, q_splits=splits)
         if not np.array_equal(got, want):
@@ -54,9 +57,10 @@ while time.time() < t_end:
             print("MISMATCH kind=%d n=%d m=%d search=%s splits=%d: %d rows" % (kind, n, m, search, splits, int((got != want).sum())), flush=True)
     # seeded iterations through the engine: all variants against exact
     outs = []
+    n_it = int(rng.randint(2, 9))
     for search in ("exact", "f32", "grid"):
         e = icp_amd.Engine(search=search)
-        e.set_target(Q); e.set_source(P); e.iterate(3)
+        e.set_target(Q); e.set_source(P); e.iterate(n_it)
         outs.append(e.get_last()["idx"]); e.close()
     if not (np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])):
         bad += 1
