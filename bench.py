@@ -187,7 +187,9 @@ def cpu_reference(P, Q, rows=4000, targets=20000):
         ok = bool(np.array_equal(idx[-len(Pz):], orc.correspondences(Pz, Qz, nthreads=4))) if len(idx) >= len(Pz) else None
         return {"value": (len(Pz) - 1) * float(len(Qz)) / dt, "unit": "distance evals/s", "cores": 1, "kind": "reference",
                 "sample": "reference get_correspondence_indices on the first %d source rows x first %d targets of the same "
-                          "clouds, %.1f s" % (len(Pz), len(Qz), dt), "indices_equal_oracle": ok}
+                          "clouds, %.1f s" % (len(Pz), len(Qz), dt), "indices_equal_oracle": ok,
+                "note": "a sub-sample, NOT the %d x %d workload: at this rate the reference needs about %.1f h per full iteration "
+                        "on one core" % (len(P), len(Q), len(P) * float(len(Q)) / ((len(Pz) - 1) * float(len(Qz)) / dt) / 3600.0)}
     except Exception as exc:   # the baseline is a report, never a reason for the bench to fail
         return {"error": repr(exc)[:200], "kind": "reference"}
 

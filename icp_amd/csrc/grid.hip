@@ -282,6 +282,10 @@ __device__ __forceinline__ void consider_rec(double ax, double ay, double az, co
 // target then has a computed d^2 >= (sqrt(D2) - delta)^2 up to a few ulp; if that still clears the tie band of the matched
 // target's new d^2, the match stands -- not even a tie is possible -- and no cell is visited.  Stored as a float rounded
 // DOWN in the upper half of rec[2i+1].w (the lower half is the index); 0 = no certificate.
+#ifndef ICPK_CERT_STEPS
+#define ICPK_CERT_STEPS 4.0
+#endif
+constexpr double kCertSteps = ICPK_CERT_STEPS;   // iterations of the present motion a fresh certificate should survive
 __device__ __forceinline__ float float_below(double v)
 {
     if (!(v > 0.0)) return 0.0f;
@@ -320,14 +324,35 @@ __global__ __launch_bounds__(kWG) void search_grid_kernel(const double *__restri
                                                           int row_cap, unsigned eval_cap, int defer_always,
                                                           uint32_t *__restrict__ ovf_count,
                                                           uint32_t *__restrict__ ovf_list, double2 *__restrict__ out_rec,
-                                                          const double *__restrict__ mot)
+                                                          const double *__restrict__ mot, double order_switch)
 {
     const size_t l = (size_t)blockIdx.x * kWG + threadIdx.x;
     if (l >= n) return;
     // order: source rows sorted by position, so that the lanes of a wave walk the same few cells (cache lines shared).
     // The rows themselves stay where they are, so everything a lane needs of its row comes from one 64-byte record
     // when the caller keeps one (prec: {x, y, z, previous index}, {that target's coordinates}).
-    const size_t i = order ? order[l] : l;
+    // Once the registration has settled, most rows keep their match by certificate without visiting a cell, and the kernel
+    // is a stream over the row records: the rows are then taken in storage order (coalesced).  "Settled" is decided from
+    // the motion record alone -- the same value in every lane of the launch, so the launch still covers every row once --
+    // as: no point of the target's bounding volume moved by more than order_switch cell half-edges.  Either order gives
+    // the same results; this only picks the faster one.
+    bool spatial = order != nullptr;
+    if (spatial && mot && idx_prev) {
+        const double o0 = mot[25], o1 = mot[26], o2 = mot[27];
+        const double c0 = ((mot[12] * o0 + mot[13] * o1) + mot[14] * o2) + mot[21] - pc[0];
+        const double c1 = ((mot[15] * o0 + mot[16] * o1) + mot[17] * o2) + mot[22] - pc[1];
+        const double c2 = ((mot[18] * o0 + mot[19] * o1) + mot[20] * o2) + mot[23] - pc[2];
+        double rot = 0.0;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const double e = mot[12 + k] - ((k % 4 == 0) ? 1.0 : 0.0);
+            rot += e * e;
+        }
+        const double ext = (g.hi[0] - g.lo[0]) + (g.hi[1] - g.lo[1]) + (g.hi[2] - g.lo[2]);
+        const double moved = sqrt(rot) * ext + ((__builtin_fabs(c0) + __builtin_fabs(c1)) + __builtin_fabs(c2));
+        spatial = !(moved <= order_switch * g.r0);   // NaN: spatial
+    }
+    const size_t i = spatial ? order[l] : l;
     double ax, ay, az, sqx = 0.0, sqy = 0.0, sqz = 0.0;
     uint32_t js = 0xFFFFFFFFu;
     double cert = 0.0, pl1 = 0.0;   // last iteration's certificate for this row; |p|_1 of the un-centred row
@@ -366,7 +391,8 @@ __global__ __launch_bounds__(kWG) void search_grid_kernel(const double *__restri
         }
     }
     double edge = dmin < INFINITY ? tie_band(dmin) : INFINITY;
-    if (cert > 0.0 && bj == js) {
+    double delta = 0.0;   // bound on how far this row moved (centred coordinates) since the previous search; 0 = unknown
+    if (mot && idx_prev && bj == js && js < m) {
         // The engine moved every row by p' = fl(R p + t) and re-centred: a' = R a + c + e with c = R Pc + t - Pc' and e the
         // rounding of the transform and of the two centrings (<= 8u of the magnitudes involved; 2^-48 = 32u is charged).
         // R is orthogonal up to the defect the solve kernel measured (mot[kSolveW + 3] = |R^T R - I|_F, required < 2^-42), so
@@ -387,16 +413,24 @@ __global__ __launch_bounds__(kWG) void search_grid_kernel(const double *__restri
         const double m1 = ay - ((mot[13] * ax + mot[16] * ay) + mot[19] * az);
         const double m2 = az - ((mot[14] * ax + mot[17] * ay) + mot[20] * az);
         if (mot[kSolveW + 3] < 0x1p-42) {
-            const double delta = (sqrt((m0 * m0 + m1 * m1) + m2 * m2) + cn) * (1.0 + 0x1p-40) + 0x1p-40 * (al1 + cn) + 0x1p-48 * mag;
-            const double room = sqrt(cert) * (1.0 - 0x1p-40) - delta;
-            const double lower = room > 0.0 ? (room * room) * (1.0 - 0x1p-40) : 0.0;   // every other target's new d^2 is above this
-            if (lower > edge) {
-                prec[2 * i + 1] = make_double4(sqx, sqy, sqz, pack_idx_cert(js, float_below(lower)));
-                return;
+            delta = (sqrt((m0 * m0 + m1 * m1) + m2 * m2) + cn) * (1.0 + 0x1p-40) + 0x1p-40 * (al1 + cn) + 0x1p-48 * mag;
+            if (cert > 0.0) {
+                const double room = sqrt(cert) * (1.0 - 0x1p-40) - delta;
+                const double lower = room > 0.0 ? (room * room) * (1.0 - 0x1p-40) : 0.0;   // every other target's new d^2 is above this
+                if (lower > edge) {
+                    prec[2 * i + 1] = make_double4(sqx, sqy, sqz, pack_idx_cert(js, float_below(lower)));
+                    return;
+                }
             }
         }
     }
     double r = first_radius(g, ax, ay, az, amax, edge);
+    // A box that just holds the sphere around the match certifies nothing beyond it (B ~ d1^2), so the next iteration's
+    // certificate would fail on any motion.  While the cloud still moves, the box is laid out wider by a few times this
+    // iteration's motion (the next ones will be of that size), at most a quarter of the radius: some more candidates now
+    // for the chance to skip the next searches of this row altogether -- unless the motion is so large that a quarter of
+    // the radius would not even buy two iterations.  A settled cloud (delta ~ 0) pays nothing.
+    if (delta > 0.0 && delta <= 0.125 * r) r += __builtin_fmin(kCertSteps * delta, 0.25 * r);
     unsigned evals = 0;
     bool defer = false;
     // Keys (two square roots each) are not needed to find the winner of a pass: d1 / d2 = the smallest and the second
@@ -452,23 +486,28 @@ __global__ __launch_bounds__(kWG) void search_grid_kernel(const double *__restri
                     break;
                 }
             }
+            // position t of the flattened sequence -> sorted position: t + (offset of the run that holds t); selects, no branches
+            const uint32_t o0 = kb[0], o1 = kb[1] - ce[0], o2 = kb[2] - ce[1], o3 = kb[3] - ce[2];
             for (uint32_t t = 0; t < total; t += 4) {
                 double4 v[4];
                 uint32_t kk[4];
 #pragma unroll
                 for (int w = 0; w < 4; ++w) {
-                    const uint32_t tt = (t + w < total) ? t + w : t;   // past the end: a record that is met anyway
-                    kk[w] = tt < ce[0] ? kb[0] + tt : tt < ce[1] ? kb[1] + (tt - ce[0]) : tt < ce[2] ? kb[2] + (tt - ce[1]) : kb[3] + (tt - ce[2]);
+                    const uint32_t tt = (t + w < total) ? t + w : t;   // past the end: a record that is met anyway (masked below)
+                    uint32_t off = o3;
+                    off = tt < ce[2] ? o2 : off;
+                    off = tt < ce[1] ? o1 : off;
+                    off = tt < ce[0] ? o0 : off;
+                    kk[w] = tt + off;
                     v[w] = rec[kk[w]];
                 }
 #pragma unroll
                 for (int w = 0; w < 4; ++w) {
-                    if (w == 0 || t + w < total) {
-                        const double d = d2_exact(ax, ay, az, v[w].x, v[w].y, v[w].z);
-                        d2 = __builtin_fmin(d2, __builtin_fmax(d, d1));
-                        k1 = d < d1 ? kk[w] : k1;
-                        d1 = __builtin_fmin(d1, d);
-                    }
+                    const double dw = d2_exact(ax, ay, az, v[w].x, v[w].y, v[w].z);
+                    const double d = (w == 0 || t + w < total) ? dw : INFINITY;
+                    d2 = __builtin_fmin(d2, __builtin_fmax(d, d1));
+                    k1 = d < d1 ? kk[w] : k1;
+                    d1 = __builtin_fmin(d1, d);
                 }
             }
         }
@@ -810,11 +849,12 @@ hipError_t search_grid(hipStream_t s, Soa3 P, size_t n, const double *pc, const 
     if (n == 0) return hipSuccess;
     if (sc && !sc->enabled) sc = nullptr;
     const int row_cap = sc ? sc->row_cap : 64, eval_cap = sc ? sc->eval_cap : 768;
+    static const double order_switch = getenv("ICP_AMD_GRID_ORDER_SWITCH") ? atof(getenv("ICP_AMD_GRID_ORDER_SWITCH")) : 0.125;
     uint32_t *cnt = sc ? sc->count2 + sc->parity : nullptr, *cnt_next = sc ? sc->count2 + (sc->parity ^ 1) : nullptr;
     search_grid_kernel<<<(unsigned)((n + kWG - 1) / kWG), kWG, 0, s>>>(P.x, P.y, P.z, pc, n, g.d, g.start, g.rec, Qz.x, Qz.y, Qz.z,
                                                                       Qz.rec, (unsigned)m, idx_prev, P.rec, order, row_cap,
                                                                       (unsigned)eval_cap, sc ? sc->defer_always : 0, cnt,
-                                                                      sc ? sc->list : nullptr, out_rec, P.rec ? motion : nullptr);
+                                                                      sc ? sc->list : nullptr, out_rec, P.rec ? motion : nullptr, order_switch);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || !sc) return e;
     size_t wgs = n < 512 ? n : 512;   // two per CU walk the queue; an empty queue (the usual case) costs the launch only

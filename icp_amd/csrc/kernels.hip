@@ -57,10 +57,10 @@ __device__ __forceinline__ double block_sum(double (&v)[NV], double *smem)
 // records that is the plain in-order sum.  The groups of one pass are summed by different threads at the same time, so
 // the dependent add chain is kSumGroup + count / kSumGroup long instead of count.
 constexpr int kSumGroup = 32;
-template <int W>
-__device__ __forceinline__ double ordered_sum(const double *__restrict__ partial, size_t count, double *stage /*[>= 256]*/)
+template <int W, int TB>   // TB = threads of the workgroup; stage holds TB doubles
+__device__ __forceinline__ double ordered_sum(const double *__restrict__ partial, size_t count, double *stage)
 {
-    constexpr int GP = kWG / W;   // groups per pass
+    constexpr int GP = TB / W;   // groups per pass
     const int col = threadIdx.x % W, gl = threadIdx.x / W;
     const size_t groups = (count + kSumGroup - 1) / kSumGroup;
     double acc = 0.0;
@@ -71,14 +71,23 @@ __device__ __forceinline__ double ordered_sum(const double *__restrict__ partial
             const size_t r0 = g * kSumGroup;
             const int recs = (int)((count - r0 < (size_t)kSumGroup) ? (count - r0) : (size_t)kSumGroup);
             const double *src = partial + r0 * W + col;
+            if (recs == kSumGroup) {   // every load of the group in flight before the first add: one memory latency, not four
+                double v[kSumGroup];
+#pragma unroll
+                for (int r = 0; r < kSumGroup; ++r) v[r] = src[(size_t)r * W];
+#pragma unroll
+                for (int r = 0; r < kSumGroup; ++r) s += v[r];
+            } else {
 #pragma unroll 8
-            for (int r = 0; r < recs; ++r) s += src[(size_t)r * W];
+                for (int r = 0; r < recs; ++r) s += src[(size_t)r * W];
+            }
         }
         __syncthreads();
         if (gl < GP) stage[gl * W + col] = s;
         __syncthreads();
         if (threadIdx.x < W) {
             const int ng = (int)((groups - g0 < (size_t)GP) ? (groups - g0) : (size_t)GP);
+#pragma unroll 8
             for (int k = 0; k < ng; ++k) acc += stage[k * W + threadIdx.x];
         }
     }
@@ -114,8 +123,8 @@ __global__ __launch_bounds__(kWG) void colsum_partials_kernel(const double *__re
 __global__ __launch_bounds__(kWG) void finalize_centroid_kernel(const double *__restrict__ partial, size_t count, double denom,
                                                                 double *__restrict__ out3)
 {
-    __shared__ double stage[256 * kCenW];
-    const double acc = ordered_sum<kCenW>(partial, count, stage);
+    __shared__ double stage[kWG];
+    const double acc = ordered_sum<kCenW, kWG>(partial, count, stage);
     if (threadIdx.x < 3) out3[threadIdx.x] = acc / denom;
 }
 
@@ -437,7 +446,7 @@ __global__ __launch_bounds__(kWG) void cov_kernel(const double *__restrict__ px,
                                                   int q_splits, const double *__restrict__ keys,
                                                   const uint32_t *__restrict__ idxs, const double2 *__restrict__ grid_rec,
                                                   const uint32_t *__restrict__ idx_in, uint32_t *__restrict__ idx_out,
-                                                  double4 *__restrict__ prec, bool result_in_prec, double reject_d2,
+                                                  double4 *__restrict__ prec, double reject_d2,
                                                   double *__restrict__ partial)
 {
     __shared__ double smem[4 * kCovW];
@@ -452,14 +461,7 @@ __global__ __launch_bounds__(kWG) void cov_kernel(const double *__restrict__ px,
         if (i < n) {
             uint32_t j;
             double q0 = 0.0, q1 = 0.0, q2 = 0.0;
-            bool have_q = false;
-            if (MERGE && result_in_prec) {   // the grid search left {matched target, idx} in the row's own record
-                const double4 v = prec[2 * i + 1];
-                j = (uint32_t)__double_as_longlong(v.w);
-                q0 = v.x; q1 = v.y; q2 = v.z;
-                have_q = true;
-                idx_out[i] = j;
-            } else if (MERGE && grid_rec) {
+            if (MERGE && grid_rec) {
                 j = (uint32_t)__double_as_longlong(grid_rec[i].y);
                 idx_out[i] = j;
             } else if (MERGE) {
@@ -479,15 +481,13 @@ __global__ __launch_bounds__(kWG) void cov_kernel(const double *__restrict__ px,
             }
             if (j < m) {
                 const double p0 = px[i] - c0, p1 = py[i] - c1, p2 = pz[i] - c2;
-                if (!have_q) {
-                    if (qrec4) {   // one 32-byte record per gathered target
-                        const double4 v = qrec4[j];
-                        q0 = v.x; q1 = v.y; q2 = v.z;
-                    } else {
-                        q0 = qx[j]; q1 = qy[j]; q2 = qz[j];
-                    }
-                    if (MERGE && prec) prec[2 * i + 1] = make_double4(q0, q1, q2, 0.0);   // the next search's seed, next to its point
+                if (qrec4) {   // one 32-byte record per gathered target
+                    const double4 v = qrec4[j];
+                    q0 = v.x; q1 = v.y; q2 = v.z;
+                } else {
+                    q0 = qx[j]; q1 = qy[j]; q2 = qz[j];
                 }
+                if (MERGE && prec) prec[2 * i + 1] = make_double4(q0, q1, q2, 0.0);   // the next search's seed, next to its point
                 // the weight hook of compute_cross_variance (src/cpu/icp.cpp:108-131: weight = kernel(p - q), a constant 1
                 // there) as a hard threshold on the pair's distance: weight 1 up to reject_d2 (+inf = the reference), else 0
                 const double d = d2_exact(p0, p1, p2, q0, q1, q2);
@@ -497,6 +497,52 @@ __global__ __launch_bounds__(kWG) void cov_kernel(const double *__restrict__ px,
                     acc[6] += q2 * p0; acc[7] += q2 * p1; acc[8] += q2 * p2;
                     acc[9] += d;
                     acc[10] += 1.0;   // pairs that entered the sums
+                }
+            }
+        }
+    }
+    const double tot = block_sum<kCovW>(acc, smem);
+    if (threadIdx.x < kCovW) partial[(size_t)blockIdx.x * kCovW + threadIdx.x] = tot;
+}
+
+// The same partial sums on the grid path with source records: everything a row needs -- its coordinates, the matched
+// target's coordinates and index -- sits in the row's own 64-byte record (search_grid_kernel wrote the second half), so a
+// workgroup streams 64 KB of whole lines, all of its loads in flight before the first use, and gathers nothing.  Same
+// arithmetic in the same order as cov_kernel<true>: bit-identical partials.
+__global__ __launch_bounds__(kWG) void cov_rec_kernel(const double4 *__restrict__ prec, size_t n, const double *__restrict__ pc,
+                                                      size_t m, uint32_t *__restrict__ idx_out, double reject_d2,
+                                                      double *__restrict__ partial)
+{
+    __shared__ double smem[4 * kCovW];
+    const double c0 = pc[0], c1 = pc[1], c2 = pc[2];
+    double acc[kCovW];
+#pragma unroll
+    for (int k = 0; k < kCovW; ++k) acc[k] = 0.0;
+    const size_t base = (size_t)blockIdx.x * kChunk + threadIdx.x;
+    double4 a[kChunk / kWG], b[kChunk / kWG];
+#pragma unroll
+    for (int k = 0; k < kChunk / kWG; ++k) {
+        const size_t i = base + (size_t)k * kWG;
+        const size_t ic = i < n ? i : n - 1;   // rows past the end: a valid address, masked below
+        a[k] = prec[2 * ic];
+        b[k] = prec[2 * ic + 1];
+    }
+#pragma unroll
+    for (int k = 0; k < kChunk / kWG; ++k) {
+        const size_t i = base + (size_t)k * kWG;
+        if (i < n) {
+            const uint32_t j = (uint32_t)__double_as_longlong(b[k].w);
+            idx_out[i] = j;
+            if (j < m) {
+                const double p0 = a[k].x - c0, p1 = a[k].y - c1, p2 = a[k].z - c2;
+                const double q0 = b[k].x, q1 = b[k].y, q2 = b[k].z;
+                const double d = d2_exact(p0, p1, p2, q0, q1, q2);
+                if (d <= reject_d2) {
+                    acc[0] += q0 * p0; acc[1] += q0 * p1; acc[2] += q0 * p2;
+                    acc[3] += q1 * p0; acc[4] += q1 * p1; acc[5] += q1 * p2;
+                    acc[6] += q2 * p0; acc[7] += q2 * p1; acc[8] += q2 * p2;
+                    acc[9] += d;
+                    acc[10] += 1.0;
                 }
             }
         }
@@ -597,15 +643,16 @@ __device__ void svd3(const double *A, double *U, double *S, double *VT)
 
 __device__ void solve_record(const double *tot, const double *pc, const double *qc, double n_global, double *out);
 
-__device__ void solve_record(const double *tot, const double *pc, const double *qc, double n_global, double *out);
-
-// One workgroup: the fixed-order sum of all chunk partials, then one lane solves.  Called by solve_kernel and by the last
-// workgroup of cov_kernel (single-GPU engines: the solve rides on the covariance launch).
-__device__ void solve_from_partials(const double *__restrict__ partial, size_t count, const double *__restrict__ pc,
-                                    const double *__restrict__ qc, double n_global, double *__restrict__ out,
-                                    double *__restrict__ extra, double *stage /* 256 * kCovW */, double *tot /* kCovW */)
+// One workgroup of kSolveWG threads: the fixed-order sum of all chunk partials (one pass of ordered_sum up to
+// 32 * (kSolveWG / kCovW) chunks = 2.7M rows: a single memory latency), then one lane solves.
+constexpr int kSolveWG = 1024;
+__global__ __launch_bounds__(kSolveWG) void solve_kernel(const double *__restrict__ partial, size_t count,
+                                                         const double *__restrict__ pc, const double *__restrict__ qc,
+                                                         double n_global, double *__restrict__ out, double *__restrict__ extra)
 {
-    const double acc = ordered_sum<kCovW>(partial, count, stage);
+    __shared__ double stage[kSolveWG];
+    __shared__ double tot[kCovW];
+    const double acc = ordered_sum<kCovW, kSolveWG>(partial, count, stage);
     if (threadIdx.x < kCovW) tot[threadIdx.x] = acc;
     __syncthreads();
     if (threadIdx.x != 0) return;
@@ -634,15 +681,6 @@ __device__ void solve_from_partials(const double *__restrict__ partial, size_t c
             }
         extra[3] = sqrt(defect);
     }
-}
-
-__global__ __launch_bounds__(kWG) void solve_kernel(const double *__restrict__ partial, size_t count,
-                                                    const double *__restrict__ pc, const double *__restrict__ qc,
-                                                    double n_global, double *__restrict__ out, double *__restrict__ extra)
-{
-    __shared__ double stage[256 * kCovW];
-    __shared__ double tot[kCovW];
-    solve_from_partials(partial, count, pc, qc, n_global, out, extra, stage, tot);
 }
 
 // One lane: cov -> SVD -> R, t; writes the 28-double record (layout in kernels.h).
@@ -1214,8 +1252,12 @@ hipError_t merge_cov(hipStream_t s, Soa3 P, size_t n, size_t n_pad, const double
 {
     if (n == 0) return hipSuccess;
     if (result_in_rec && !P.rec) return hipErrorInvalidValue;
+    if (result_in_rec) {
+        cov_rec_kernel<<<blocks_for(n, kChunk), kWG, 0, s>>>(P.rec, n, pc, m, idx_out, reject_d2, partial);
+        return hipGetLastError();
+    }
     cov_kernel<true><<<blocks_for(n, kChunk), kWG, 0, s>>>(P.x, P.y, P.z, n, n_pad, pc, Qz.x, Qz.y, Qz.z, Qz.rec, m, q_splits, keys,
-                                                           idxs, grid_rec, nullptr, idx_out, P.rec, result_in_rec, reject_d2, partial);
+                                                           idxs, grid_rec, nullptr, idx_out, P.rec, reject_d2, partial);
     return hipGetLastError();
 }
 
@@ -1224,14 +1266,14 @@ hipError_t cov_from_idx(hipStream_t s, Soa3 P, size_t n, const double *pc, Soa3 
 {
     if (n == 0) return hipSuccess;
     cov_kernel<false><<<blocks_for(n, kChunk), kWG, 0, s>>>(P.x, P.y, P.z, n, 0, pc, Qz.x, Qz.y, Qz.z, Qz.rec, m, 1, nullptr, nullptr,
-                                                            nullptr, idx, nullptr, nullptr, false, INFINITY, partial);
+                                                            nullptr, idx, nullptr, nullptr, INFINITY, partial);
     return hipGetLastError();
 }
 
 hipError_t solve(hipStream_t s, const double *partial, size_t count, const double *pc, const double *qc, double n_global,
                  double *out, double *extra)
 {
-    solve_kernel<<<1, kWG, 0, s>>>(partial, count, pc, qc, n_global, out, extra);
+    solve_kernel<<<1, kSolveWG, 0, s>>>(partial, count, pc, qc, n_global, out, extra);
     return hipGetLastError();
 }
 
