@@ -71,12 +71,14 @@ def roofline(variant, n_local, M, avg_ms, launches):
                 "avg_launch_ms": avg_ms, "launches": launches, "traffic": None, "variant": variant,
                 "mfma_flops_issued_per_pair": 32, "mfma_issued_tflops": issued / 1e12, "mfma_pipe_frac": issued / PEAK_F16_MFMA,
                 "valu_floor_ms": valu_floor_ms, "frac_of_valu_floor": valu_floor_ms / avg_ms if avg_ms > 0 else 0.0,
-                "instruction_mix": "fast path = fp16 MFMA pre-filter (operands split into hi + lo fp16 pieces, 15 of the 16 K slots "
-                                   "used) + 0.5 v_min3_f32 per pair on the VALU, co-executing; every candidate re-evaluated in "
+                "instruction_mix": "fast path = fp16 MFMA pre-filter (operands split into hi + lo fp16 pieces, 11 of the 16 K slots "
+                                   "non-zero) + 0.5 v_min3_f32 per pair on the VALU, co-executing; every candidate re-evaluated in "
                                    "un-fused fp64 (indices bit-identical to the fp64 variants)",
                 "note": "`achieved` counts the ALGORITHMIC 8 flops per pair against the dense f16 MFMA peak (2.5 PFLOP/s); the "
-                        "matrix pipe itself is `mfma_pipe_frac` busy (32 issued flops per pair), and what binds the kernel is "
-                        "VALU issue: `valu_floor_ms` is the time of its half v_min3_f32 per pair alone"}
+                        "matrix pipe itself is `mfma_pipe_frac` busy at the nominal 2.4 GHz (32 issued flops per pair).  The kernel "
+                        "is POWER bound: its MFMA stream alone runs at 1.63 GHz on random operands (20.7 ms for this launch) "
+                        "against 2.39 GHz on zeros (13.8 ms), profiles/r2_ubench_mfma.txt; `valu_floor_ms` is the time of its half "
+                        "v_min3_f32 per pair alone"}
     f32 = variant == "f32"
     peak = PEAK_FP32_VALU if f32 else PEAK_FP64_VALU_NOFMA
     mix = {"f32": "fast path = fp32 pre-filter, 3 v_fma_f32 (or 1.5 v_pk_fma_f32) + 0.5 v_min3_f32 per pair; every candidate "

@@ -8,7 +8,9 @@
 //
 //  * cell_of() is a composition of monotone rounded operations, and the SAME function files the targets into cells
 //    and maps the corners of a query box [a - r, a + r] to the cell range that is visited.  A target outside the
-//    visited range therefore lies strictly outside the box along at least one axis, e.g. t.x < xlo = fl(a.x - r).
+//    visited range therefore lies strictly outside the box along at least one axis, e.g. t.x < xlo = fl(a.x - r)
+//    (and even below any xe < xlo that cell_of() still maps into the visited range: reach_lo / reach_hi take xe
+//    next to the outer edge of the visited cells, so the bound counts the whole of the cells that were searched).
 //  * its computed difference fl(a.x - t.x) is then >= g = fl(a.x - xlo), and since squares and sums of non-negative
 //    terms round monotonically its computed d^2 is >= fl(g * g).  B = the smallest such bound over the box faces
 //    that have cells beyond them.
@@ -22,6 +24,7 @@
 #include "exact.h"
 
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -192,6 +195,23 @@ struct Box {
     double B;
     bool all;   // the box covers the whole grid
 };
+// How far the VISITED CELLS reach beyond the box along one axis.  Every target of the cells c0..c1 is evaluated, not only
+// those inside the box, so the unvisited targets lie beyond the outer edges of those cells, which is further out than the
+// box faces (half a cell on average -- as much again as the distance to the match: a much stronger bound for the same
+// work, which ends searches earlier and lets certificates outlive more motion).  The edge is not trusted as arithmetic:
+// xe = a point 2^-20 of a cell inside the edge, accepted only if cell_of() -- the function that filed the targets -- maps
+// it into the visited range.  Then an unvisited target t below the range has cell_of(t) < c0 <= cell_of(xe), hence t < xe
+// by monotonicity, exactly the property the box face xlo has (and falls back to: cell_of(xlo) = c0 by construction).
+__device__ __forceinline__ double reach_lo(double xlo, int c0, double lo, double inv, double h, int dim)
+{
+    const double xe = lo + ((double)c0 + 0x1p-20) * h;
+    return (xe < xlo && cell_of(xe, lo, inv, dim) >= c0) ? xe : xlo;
+}
+__device__ __forceinline__ double reach_hi(double xhi, int c1, double lo, double inv, double h, int dim)
+{
+    const double xe = lo + ((double)(c1 + 1) - 0x1p-20) * h;
+    return (xe > xhi && cell_of(xe, lo, inv, dim) <= c1) ? xe : xhi;
+}
 __device__ __forceinline__ Box make_box(const GridDesc &g, double ax, double ay, double az, double r)
 {
     Box b;
@@ -203,12 +223,12 @@ __device__ __forceinline__ Box make_box(const GridDesc &g, double ax, double ay,
     b.cz0 = cell_of(zlo, g.lo[2], g.inv[2], g.dim[2]);
     b.cz1 = cell_of(zhi, g.lo[2], g.inv[2], g.dim[2]);
     double B = INFINITY;
-    if (b.cx0 > 0) { const double t = ax - xlo; B = __builtin_fmin(B, t * t); }
-    if (b.cx1 < g.dim[0] - 1) { const double t = xhi - ax; B = __builtin_fmin(B, t * t); }
-    if (b.cy0 > 0) { const double t = ay - ylo; B = __builtin_fmin(B, t * t); }
-    if (b.cy1 < g.dim[1] - 1) { const double t = yhi - ay; B = __builtin_fmin(B, t * t); }
-    if (b.cz0 > 0) { const double t = az - zlo; B = __builtin_fmin(B, t * t); }
-    if (b.cz1 < g.dim[2] - 1) { const double t = zhi - az; B = __builtin_fmin(B, t * t); }
+    if (b.cx0 > 0) { const double t = ax - reach_lo(xlo, b.cx0, g.lo[0], g.inv[0], g.h[0], g.dim[0]); B = __builtin_fmin(B, t * t); }
+    if (b.cx1 < g.dim[0] - 1) { const double t = reach_hi(xhi, b.cx1, g.lo[0], g.inv[0], g.h[0], g.dim[0]) - ax; B = __builtin_fmin(B, t * t); }
+    if (b.cy0 > 0) { const double t = ay - reach_lo(ylo, b.cy0, g.lo[1], g.inv[1], g.h[1], g.dim[1]); B = __builtin_fmin(B, t * t); }
+    if (b.cy1 < g.dim[1] - 1) { const double t = reach_hi(yhi, b.cy1, g.lo[1], g.inv[1], g.h[1], g.dim[1]) - ay; B = __builtin_fmin(B, t * t); }
+    if (b.cz0 > 0) { const double t = az - reach_lo(zlo, b.cz0, g.lo[2], g.inv[2], g.h[2], g.dim[2]); B = __builtin_fmin(B, t * t); }
+    if (b.cz1 < g.dim[2] - 1) { const double t = reach_hi(zhi, b.cz1, g.lo[2], g.inv[2], g.h[2], g.dim[2]) - az; B = __builtin_fmin(B, t * t); }
     b.B = B;
     b.all = b.cx0 == 0 && b.cy0 == 0 && b.cz0 == 0 && b.cx1 == g.dim[0] - 1 && b.cy1 == g.dim[1] - 1 && b.cz1 == g.dim[2] - 1;
     return b;
@@ -282,10 +302,6 @@ __device__ __forceinline__ void consider_rec(double ax, double ay, double az, co
 // target then has a computed d^2 >= (sqrt(D2) - delta)^2 up to a few ulp; if that still clears the tie band of the matched
 // target's new d^2, the match stands -- not even a tie is possible -- and no cell is visited.  Stored as a float rounded
 // DOWN in the upper half of rec[2i+1].w (the lower half is the index); 0 = no certificate.
-#ifndef ICPK_CERT_STEPS
-#define ICPK_CERT_STEPS 4.0
-#endif
-constexpr double kCertSteps = ICPK_CERT_STEPS;   // iterations of the present motion a fresh certificate should survive
 __device__ __forceinline__ float float_below(double v)
 {
     if (!(v > 0.0)) return 0.0f;
@@ -324,10 +340,10 @@ __global__ __launch_bounds__(kWG) void search_grid_kernel(const double *__restri
                                                           int row_cap, unsigned eval_cap, int defer_always,
                                                           uint32_t *__restrict__ ovf_count,
                                                           uint32_t *__restrict__ ovf_list, double2 *__restrict__ out_rec,
-                                                          const double *__restrict__ mot, double order_switch)
+                                                          const double *__restrict__ mot, double order_switch,
+                                                          unsigned long long *__restrict__ stat)
 {
     const size_t l = (size_t)blockIdx.x * kWG + threadIdx.x;
-    if (l >= n) return;
     // order: source rows sorted by position, so that the lanes of a wave walk the same few cells (cache lines shared).
     // The rows themselves stay where they are, so everything a lane needs of its row comes from one 64-byte record
     // when the caller keeps one (prec: {x, y, z, previous index}, {that target's coordinates}).
@@ -352,85 +368,105 @@ __global__ __launch_bounds__(kWG) void search_grid_kernel(const double *__restri
         const double moved = sqrt(rot) * ext + ((__builtin_fabs(c0) + __builtin_fabs(c1)) + __builtin_fabs(c2));
         spatial = !(moved <= order_switch * g.r0);   // NaN: spatial
     }
-    const size_t i = spatial ? order[l] : l;
-    double ax, ay, az, sqx = 0.0, sqy = 0.0, sqz = 0.0;
-    uint32_t js = 0xFFFFFFFFu;
-    double cert = 0.0, pl1 = 0.0;   // last iteration's certificate for this row; |p|_1 of the un-centred row
-    if (prec) {
-        const double4 v0 = prec[2 * i], v1 = prec[2 * i + 1];
-        ax = v0.x - pc[0]; ay = v0.y - pc[1]; az = v0.z - pc[2];
-        if (idx_prev) js = (uint32_t)__double_as_longlong(v0.w);
-        sqx = v1.x; sqy = v1.y; sqz = v1.z;
-        if (idx_prev && mot) {
-            const unsigned long long w1 = (unsigned long long)__double_as_longlong(v1.w);
-            if ((uint32_t)w1 == js) cert = (double)__uint_as_float((uint32_t)(w1 >> 32));   // belongs to this seed
-            pl1 = (__builtin_fabs(v0.x) + __builtin_fabs(v0.y)) + __builtin_fabs(v0.z);
+    size_t i = spatial ? order[l < n ? l : n - 1] : l;
+    double ax = 0.0, ay = 0.0, az = 0.0, sqx = 0.0, sqy = 0.0, sqz = 0.0, cert = 0.0, pl1 = 0.0, dmin = INFINITY, edge = INFINITY;
+    double delta = 0.0, amax = 0.0;   // delta: bound on how far the row moved (centred coordinates) since the previous search; 0 = unknown
+    uint32_t js = 0xFFFFFFFFu, bj = 0xFFFFFFFFu;
+    // Everything that precedes the walk over the cells, for row i: true = the row has to walk (its state is in the variables
+    // above), false = its result is written (certificate held, or no finite coordinates).
+    auto setup = [&]() -> bool {
+        sqx = sqy = sqz = 0.0;
+        js = 0xFFFFFFFFu;
+        cert = 0.0; pl1 = 0.0;   // last iteration's certificate for this row; |p|_1 of the un-centred row
+        if (prec) {
+            const double4 v0 = prec[2 * i], v1 = prec[2 * i + 1];
+            ax = v0.x - pc[0]; ay = v0.y - pc[1]; az = v0.z - pc[2];
+            if (idx_prev) js = (uint32_t)__double_as_longlong(v0.w);
+            sqx = v1.x; sqy = v1.y; sqz = v1.z;
+            if (idx_prev && mot) {
+                const unsigned long long w1 = (unsigned long long)__double_as_longlong(v1.w);
+                if ((uint32_t)w1 == js) cert = (double)__uint_as_float((uint32_t)(w1 >> 32));   // belongs to this seed
+                pl1 = (__builtin_fabs(v0.x) + __builtin_fabs(v0.y)) + __builtin_fabs(v0.z);
+            }
+        } else {
+            ax = px[i] - pc[0]; ay = py[i] - pc[1]; az = pz[i] - pc[2];
+            if (idx_prev) js = idx_prev[i];
         }
-    } else {
-        ax = px[i] - pc[0]; ay = py[i] - pc[1]; az = pz[i] - pc[2];
-        if (idx_prev) js = idx_prev[i];
-    }
-    double dmin = INFINITY;   // oracle: min_dist = DBL_MAX on the key, idx = -1
-    uint32_t bj = 0xFFFFFFFFu;
-    const double amax = __builtin_fmax(__builtin_fmax(__builtin_fabs(ax), __builtin_fabs(ay)), __builtin_fabs(az));
-    if (!(amax < INFINITY) || ax != ax || ay != ay || az != az) {   // every d^2 is inf or NaN: no correspondence
-        if (prec) prec[2 * i + 1] = make_double4(0.0, 0.0, 0.0, __longlong_as_double((long long)bj));
-        else out_rec[i] = make_double2(INFINITY, __longlong_as_double((long long)bj));
-        return;
-    }
-    if (!prec && js < m) {   // the coordinates of the seed
-        sqx = qrec4 ? qrec4[js].x : qx[js];
-        sqy = qrec4 ? qrec4[js].y : qy[js];
-        sqz = qrec4 ? qrec4[js].z : qz[js];
-    }
-    if (js < m) {
-        const double d = d2_exact(ax, ay, az, sqx, sqy, sqz);
-        if (d < INFINITY) {
-            dmin = d;
-            bj = js;
+        dmin = INFINITY;   // oracle: min_dist = DBL_MAX on the key, idx = -1
+        bj = 0xFFFFFFFFu;
+        amax = __builtin_fmax(__builtin_fmax(__builtin_fabs(ax), __builtin_fabs(ay)), __builtin_fabs(az));
+        if (!(amax < INFINITY) || ax != ax || ay != ay || az != az) {   // every d^2 is inf or NaN: no correspondence
+            if (prec) prec[2 * i + 1] = make_double4(0.0, 0.0, 0.0, __longlong_as_double((long long)bj));
+            else out_rec[i] = make_double2(INFINITY, __longlong_as_double((long long)bj));
+            return false;
         }
-    }
-    double edge = dmin < INFINITY ? tie_band(dmin) : INFINITY;
-    double delta = 0.0;   // bound on how far this row moved (centred coordinates) since the previous search; 0 = unknown
-    if (mot && idx_prev && bj == js && js < m) {
-        // The engine moved every row by p' = fl(R p + t) and re-centred: a' = R a + c + e with c = R Pc + t - Pc' and e the
-        // rounding of the transform and of the two centrings (<= 8u of the magnitudes involved; 2^-48 = 32u is charged).
-        // R is orthogonal up to the defect the solve kernel measured (mot[kSolveW + 3] = |R^T R - I|_F, required < 2^-42), so
-        // a = R^T (a' - c - e) up to 2^-40 (|a'| + |c|), and the row moved by  a' - a = (I - R^T) a' + R^T (c + e):
-        //     |a' - a| <= |(I - R^T) a'| + |c| + eps.
-        // mot = the solve record of that motion: R at [12..20], t at [21..23], the old Pc at [25..27]; pc = the new centroid.
-        const double o0 = mot[25], o1 = mot[26], o2 = mot[27], t0 = mot[21], t1 = mot[22], t2 = mot[23];
-        const double c0 = ((mot[12] * o0 + mot[13] * o1) + mot[14] * o2) + t0 - pc[0];
-        const double c1 = ((mot[15] * o0 + mot[16] * o1) + mot[17] * o2) + t1 - pc[1];
-        const double c2 = ((mot[18] * o0 + mot[19] * o1) + mot[20] * o2) + t2 - pc[2];
-        const double cn = (__builtin_fabs(c0) + __builtin_fabs(c1)) + __builtin_fabs(c2);          // >= |c|_2
-        const double mag = pl1 + ((__builtin_fabs(t0) + __builtin_fabs(t1)) + __builtin_fabs(t2)) +
-                           ((__builtin_fabs(o0) + __builtin_fabs(o1)) + __builtin_fabs(o2)) +
-                           ((__builtin_fabs(pc[0]) + __builtin_fabs(pc[1])) + __builtin_fabs(pc[2]));
-        const double al1 = (__builtin_fabs(ax) + __builtin_fabs(ay)) + __builtin_fabs(az);          // >= |a'|_2
-        // (I - R^T) a': row k of R^T is column k of R
-        const double m0 = ax - ((mot[12] * ax + mot[15] * ay) + mot[18] * az);
-        const double m1 = ay - ((mot[13] * ax + mot[16] * ay) + mot[19] * az);
-        const double m2 = az - ((mot[14] * ax + mot[17] * ay) + mot[20] * az);
-        if (mot[kSolveW + 3] < 0x1p-42) {
-            delta = (sqrt((m0 * m0 + m1 * m1) + m2 * m2) + cn) * (1.0 + 0x1p-40) + 0x1p-40 * (al1 + cn) + 0x1p-48 * mag;
-            if (cert > 0.0) {
-                const double room = sqrt(cert) * (1.0 - 0x1p-40) - delta;
-                const double lower = room > 0.0 ? (room * room) * (1.0 - 0x1p-40) : 0.0;   // every other target's new d^2 is above this
-                if (lower > edge) {
-                    prec[2 * i + 1] = make_double4(sqx, sqy, sqz, pack_idx_cert(js, float_below(lower)));
-                    return;
+        if (!prec && js < m) {   // the coordinates of the seed
+            sqx = qrec4 ? qrec4[js].x : qx[js];
+            sqy = qrec4 ? qrec4[js].y : qy[js];
+            sqz = qrec4 ? qrec4[js].z : qz[js];
+        }
+        if (js < m) {
+            const double d = d2_exact(ax, ay, az, sqx, sqy, sqz);
+            if (d < INFINITY) {
+                dmin = d;
+                bj = js;
+            }
+        }
+        edge = dmin < INFINITY ? tie_band(dmin) : INFINITY;
+        delta = 0.0;
+        if (mot && idx_prev && bj == js && js < m) {
+            // The engine moved every row by p' = fl(R p + t) and re-centred: a' = R a + c + e with c = R Pc + t - Pc' and e the
+            // rounding of the transform and of the two centrings (<= 8u of the magnitudes involved; 2^-48 = 32u is charged).
+            // R is orthogonal up to the defect the solve kernel measured (mot[kSolveW + 3] = |R^T R - I|_F, required < 2^-42), so
+            // a = R^T (a' - c - e) up to 2^-40 (|a'| + |c|), and the row moved by  a' - a = (I - R^T) a' + R^T (c + e):
+            //     |a' - a| <= |(I - R^T) a'| + |c| + eps.
+            // mot = the solve record of that motion: R at [12..20], t at [21..23], the old Pc at [25..27]; pc = the new centroid.
+            const double o0 = mot[25], o1 = mot[26], o2 = mot[27], t0 = mot[21], t1 = mot[22], t2 = mot[23];
+            const double c0 = ((mot[12] * o0 + mot[13] * o1) + mot[14] * o2) + t0 - pc[0];
+            const double c1 = ((mot[15] * o0 + mot[16] * o1) + mot[17] * o2) + t1 - pc[1];
+            const double c2 = ((mot[18] * o0 + mot[19] * o1) + mot[20] * o2) + t2 - pc[2];
+            const double cn = (__builtin_fabs(c0) + __builtin_fabs(c1)) + __builtin_fabs(c2);          // >= |c|_2
+            const double mag = pl1 + ((__builtin_fabs(t0) + __builtin_fabs(t1)) + __builtin_fabs(t2)) +
+                               ((__builtin_fabs(o0) + __builtin_fabs(o1)) + __builtin_fabs(o2)) +
+                               ((__builtin_fabs(pc[0]) + __builtin_fabs(pc[1])) + __builtin_fabs(pc[2]));
+            const double al1 = (__builtin_fabs(ax) + __builtin_fabs(ay)) + __builtin_fabs(az);          // >= |a'|_2
+            // (I - R^T) a': row k of R^T is column k of R
+            const double m0 = ax - ((mot[12] * ax + mot[15] * ay) + mot[18] * az);
+            const double m1 = ay - ((mot[13] * ax + mot[16] * ay) + mot[19] * az);
+            const double m2 = az - ((mot[14] * ax + mot[17] * ay) + mot[20] * az);
+            if (mot[kSolveW + 3] < 0x1p-42) {
+                delta = (sqrt((m0 * m0 + m1 * m1) + m2 * m2) + cn) * (1.0 + 0x1p-40) + 0x1p-40 * (al1 + cn) + 0x1p-48 * mag;
+                if (cert > 0.0) {
+                    const double room = sqrt(cert) * (1.0 - 0x1p-40) - delta;
+                    const double lower = room > 0.0 ? (room * room) * (1.0 - 0x1p-40) : 0.0;   // every other target's new d^2 is above this
+                    if (lower > edge) {
+                        prec[2 * i + 1] = make_double4(sqx, sqy, sqz, pack_idx_cert(js, float_below(lower)));
+                        return false;
+                    }
                 }
             }
         }
+        return true;
+    };
+    // Rows that walk are rare once certificates hold, but nearly every wave has a few, and a wave is as slow as its slowest
+    // lane: the workgroup gathers its walking rows and packs them into as few waves as they need; the other waves leave.
+    __shared__ uint32_t s_walk[kWG];
+    __shared__ uint32_t s_walkers;
+    if (threadIdx.x == 0) s_walkers = 0;
+    __syncthreads();
+    bool need = l < n && setup();
+    if (need) s_walk[atomicAdd(&s_walkers, 1u)] = (uint32_t)i;
+    __syncthreads();
+    const uint32_t walkers = s_walkers;
+    if (stat && threadIdx.x == 0) atomicAdd(&stat[0], (unsigned long long)walkers);
+    const size_t left = n - (size_t)blockIdx.x * kWG;
+    if (walkers + 64 <= (left < (size_t)kWG ? left : (size_t)kWG)) {   // packing frees at least one wave
+        if (threadIdx.x >= walkers) return;
+        i = s_walk[threadIdx.x];
+        need = setup();   // the same decision again (walking rows have written nothing), now with this row's state
     }
+    if (!need) return;
     double r = first_radius(g, ax, ay, az, amax, edge);
-    // A box that just holds the sphere around the match certifies nothing beyond it (B ~ d1^2), so the next iteration's
-    // certificate would fail on any motion.  While the cloud still moves, the box is laid out wider by a few times this
-    // iteration's motion (the next ones will be of that size), at most a quarter of the radius: some more candidates now
-    // for the chance to skip the next searches of this row altogether -- unless the motion is so large that a quarter of
-    // the radius would not even buy two iterations.  A settled cloud (delta ~ 0) pays nothing.
-    if (delta > 0.0 && delta <= 0.125 * r) r += __builtin_fmin(kCertSteps * delta, 0.25 * r);
     unsigned evals = 0;
     bool defer = false;
     // Keys (two square roots each) are not needed to find the winner of a pass: d1 / d2 = the smallest and the second
@@ -555,6 +591,7 @@ __global__ __launch_bounds__(kWG) void search_grid_kernel(const double *__restri
     if (prec) prec[2 * i + 1] = make_double4(sqx, sqy, sqz, pack_idx_cert(bj, c));
     else out_rec[i] = make_double2(dmin, __longlong_as_double((long long)bj));
     if (defer) ovf_list[atomicAdd(ovf_count, 1u)] = (uint32_t)i;
+    if (stat) atomicAdd(&stat[1], (unsigned long long)evals);
 }
 
 // The queued points, one workgroup each: the 256 lanes walk the box together (waves take rows of cells, lanes stride
@@ -703,6 +740,7 @@ static void choose_cells(const double lo[3], const double hi[3], size_t m, doubl
         d->hi[k] = hi[k];
         d->inv[k] = ext[k] > 0.0 ? (double)d->dim[k] / ext[k] : 0.0;
         if (!(d->inv[k] < INFINITY)) { d->inv[k] = 0.0; d->dim[k] = 1; }   // extent so small that dim/ext overflows
+        d->h[k] = d->dim[k] > 1 ? ext[k] / d->dim[k] : 0.0;
         if (d->dim[k] > 1) hmin = fmin(hmin, ext[k] / d->dim[k]);
     }
     d->r0 = hmin < INFINITY ? 0.5 * hmin : 1.0;
@@ -842,6 +880,7 @@ hipError_t grid_order(hipStream_t s, Soa3 P, size_t n, uint32_t *order)
     return e;
 }
 
+constexpr unsigned kStatSlots = 4096;
 hipError_t search_grid(hipStream_t s, Soa3 P, size_t n, const double *pc, const Grid &g, Soa3 Qz, size_t m,
                        const uint32_t *idx_prev, const uint32_t *order, GridScratch *sc, double2 *out_rec, const double *motion)
 {
@@ -854,7 +893,8 @@ hipError_t search_grid(hipStream_t s, Soa3 P, size_t n, const double *pc, const 
     search_grid_kernel<<<(unsigned)((n + kWG - 1) / kWG), kWG, 0, s>>>(P.x, P.y, P.z, pc, n, g.d, g.start, g.rec, Qz.x, Qz.y, Qz.z,
                                                                       Qz.rec, (unsigned)m, idx_prev, P.rec, order, row_cap,
                                                                       (unsigned)eval_cap, sc ? sc->defer_always : 0, cnt,
-                                                                      sc ? sc->list : nullptr, out_rec, P.rec ? motion : nullptr, order_switch);
+                                                                      sc ? sc->list : nullptr, out_rec, P.rec ? motion : nullptr, order_switch,
+                                                                      (sc && sc->stat) ? sc->stat + 2 * (sc->stat_slot++ % kStatSlots) : nullptr);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || !sc) return e;
     size_t wgs = n < 512 ? n : 512;   // two per CU walk the queue; an empty queue (the usual case) costs the launch only
@@ -874,6 +914,10 @@ hipError_t grid_scratch_alloc(hipStream_t s, size_t n, GridScratch *sc)
     hipError_t e = dmalloc(&sc->count2, 2 * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMemsetAsync(sc->count2, 0, 2 * sizeof(uint32_t), s);   // s: the stream the searches will run on
     if (e == hipSuccess) e = dmalloc(&sc->list, (n ? n : 1) * sizeof(uint32_t));
+    if (e == hipSuccess && getenv("ICP_AMD_GRID_STATS") && atoi(getenv("ICP_AMD_GRID_STATS"))) {
+        e = dmalloc(&sc->stat, 2 * kStatSlots * sizeof(unsigned long long));
+        if (e == hipSuccess) e = hipMemsetAsync(sc->stat, 0, 2 * kStatSlots * sizeof(unsigned long long), s);
+    }
     if (e == hipSuccess) e = hipHostMalloc((void **)&sc->host_mem, sizeof(uint32_t), hipHostMallocMapped);
     if (e == hipSuccess) {
         *sc->host_mem = 0;
@@ -886,6 +930,15 @@ hipError_t grid_scratch_alloc(hipStream_t s, size_t n, GridScratch *sc)
 void grid_scratch_free(GridScratch *sc)
 {
     if (!sc) return;
+    if (sc->stat) {
+        const unsigned used = sc->stat_slot < kStatSlots ? sc->stat_slot : kStatSlots;
+        unsigned long long *h = (unsigned long long *)malloc(2 * kStatSlots * sizeof(unsigned long long));
+        if (h && hipDeviceSynchronize() == hipSuccess &&
+            hipMemcpy(h, sc->stat, 2 * kStatSlots * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess)
+            for (unsigned k = 0; k < used; ++k) fprintf(stderr, "grid search %u: %llu rows walked, %llu targets evaluated\n", k, h[2 * k], h[2 * k + 1]);
+        free(h);
+        (void)dfree(sc->stat);
+    }
     if (sc->count2) (void)dfree(sc->count2);
     if (sc->list) (void)dfree(sc->list);
     if (sc->host_mem) (void)hipHostFree((void *)sc->host_mem);

@@ -87,6 +87,7 @@ hipError_t grid_warmup(hipStream_t s);
 struct GridDesc {
     double lo[3], hi[3];   // bounding box of the targets
     double inv[3];         // cells per unit length along each axis (0 for an axis of zero extent)
+    double h[3];           // cell edge along each axis (about 1 / inv; only ever used through a check by cell_of())
     int dim[3];            // cells per axis
     double r0;             // first search radius of an un-seeded query that lies inside the box (half a cell)
 };
@@ -115,6 +116,8 @@ struct GridScratch {
     int parity = 0;
     int row_cap = 64, eval_cap = 768;       // rows of cells / targets one lane walks alone (read from the environment at allocation)
     int defer_always = 0;                   // 1: hand over every box above the caps (tests); 0: only when most of the wave would idle
+    unsigned long long *stat = nullptr;     // ICP_AMD_GRID_STATS=1 (diagnostics): per launch {rows that walked cells, targets evaluated},
+    unsigned stat_slot = 0;                 // printed to stderr when the scratch is released
     bool enabled = true;                    // false: this launch hands nothing over (every lane finishes its own point) and the
                                             // overflow kernel is not launched -- the caller's choice while the queue stays empty
 };

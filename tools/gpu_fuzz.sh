@@ -11,4 +11,5 @@ run() { # name seconds seed
   timeout -k 10 $(( $2 + 120 )) python -u tests/fuzz/$1.py $2 $3 > $O/$1.txt 2>&1 || { echo "$1 FAILED"; tail -8 $O/$1.txt; exit 1; }
   echo "$1: $(tail -1 $O/$1.txt)"
 }
-run fuzz_variants 200 21 && run fuzz_big 260 22 && run fuzz_sharded 100 23 && run fuzz_hooks 60 24 && run fuzz_batch 60 25
+S=${2:-20}
+run fuzz_variants 200 $((S+1)) && run fuzz_big 260 $((S+2)) && run fuzz_sharded 100 $((S+3)) && run fuzz_hooks 60 $((S+4)) && run fuzz_batch 60 $((S+5))
