@@ -888,7 +888,8 @@ hipError_t search_grid(hipStream_t s, Soa3 P, size_t n, const double *pc, const 
     if (n == 0) return hipSuccess;
     if (sc && !sc->enabled) sc = nullptr;
     const int row_cap = sc ? sc->row_cap : 64, eval_cap = sc ? sc->eval_cap : 768;
-    static const double order_switch = getenv("ICP_AMD_GRID_ORDER_SWITCH") ? atof(getenv("ICP_AMD_GRID_ORDER_SWITCH")) : 0.125;
+    const char *sw = getenv("ICP_AMD_GRID_ORDER_SWITCH");   // read per launch: tests flip it inside one process
+    const double order_switch = sw ? atof(sw) : 0.125;
     uint32_t *cnt = sc ? sc->count2 + sc->parity : nullptr, *cnt_next = sc ? sc->count2 + (sc->parity ^ 1) : nullptr;
     search_grid_kernel<<<(unsigned)((n + kWG - 1) / kWG), kWG, 0, s>>>(P.x, P.y, P.z, pc, n, g.d, g.start, g.rec, Qz.x, Qz.y, Qz.z,
                                                                       Qz.rec, (unsigned)m, idx_prev, P.rec, order, row_cap,

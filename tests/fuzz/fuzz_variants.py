@@ -50,6 +50,9 @@ while time.time() < t_end:
     # half the cases run the brute-force launches truly un-seeded (the cooperative exact path of the matrix filter), the
     # other half seeded from the grid's answer like the engine's first iteration
     os.environ["ICP_AMD_GRID_SEED"] = "0" if rng.rand() < 0.5 else "1"
+    # the grid's processing order of the rows (spatial / storage, and where it switches) and its cell size never matter
+    os.environ["ICP_AMD_GRID_ORDER_SWITCH"] = str(rng.choice([0.0, 0.125, 4.0, 1e30]))
+    os.environ["ICP_AMD_GRID_PER_CELL"] = str(rng.choice([0.5, 1.0, 2.0, 2.0, 6.0]))
     for search, splits in (("exact", 1), ("fma", int(rng.randint(1, 9))), ("f32", int(rng.randint(1, 9))), ("grid", 1)):
         got = icp_amd.correspondences(P, Pc, Qz, search=search, q_splits=splits)
         if not np.array_equal(got, want):

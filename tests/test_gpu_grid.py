@@ -311,3 +311,74 @@ def test_motion_certificate_is_void_after_two_updates_without_a_search():
     assert np.array_equal(a.get_source(), b.get_source())
     a.close()
     b.close()
+
+
+def test_bound_from_the_visited_cells_with_targets_on_cell_edges(monkeypatch):
+    """The bound on what a search has NOT visited counts the whole of the visited cells (grid.hip reach_lo / reach_hi): the
+    coordinate next to the cells' outer edge is accepted only through cell_of().  Worst case for that: a target lattice whose
+    points sit exactly ON the cell edges (17^3 integer points, 16^3 cells of edge exactly 1), queries on the edges, a hair
+    off them (2^-20 and 2^-21 of a cell: the inset the code uses, and half of it), at cell centres and at random; the grid
+    must return the oracle's index -- lowest index among exact ties -- stage by stage and through seeded engine iterations."""
+    monkeypatch.setenv("ICP_AMD_GRID_PER_CELL", "1.2")
+    monkeypatch.setenv("ICP_AMD_GRID_REFINE", "0")
+    rng = np.random.RandomState(11)
+    ax = np.arange(0, 17, dtype=np.float64)
+    Q = np.stack(np.meshgrid(ax, ax, ax, indexing="ij"), -1).reshape(-1, 3)
+    Q = Q[rng.permutation(len(Q))]
+    Qz = Q - orc.mean0(Q)
+    assert np.array_equal(orc.mean0(Q), np.full(3, 8.0))
+    base = Qz[rng.permutation(len(Qz))[:1500]]
+    parts = [base[:300]]
+    for off in (0.5, 2.0 ** -20, -2.0 ** -20, 2.0 ** -21, -2.0 ** -21, 1.0 - 2.0 ** -20, 0.25, 1e-9):
+        parts.append(base[:300] + off)
+        parts.append(base[300:600] + np.array([off, 0.0, -off]))
+        parts.append(base[600:900] + np.array([0.0, off, 0.5]))
+    parts.append(rng.uniform(-9.5, 9.5, (3000, 3)))
+    P = np.concatenate(parts)
+    want = orc.correspondences(P, Qz)
+    for search in ("grid", "exact"):
+        assert np.array_equal(icp_amd.correspondences(P, np.zeros(3), Qz, search=search), want), search
+    prev = np.roll(want, 3)          # a seed that is wrong for every row: the first box comes from the seed's distance
+    assert np.array_equal(icp_amd.correspondences_seeded(P, np.zeros(3), Qz, prev, search="grid"), want)
+    outs = []
+    for search in ("grid", "exact"):
+        e = icp_amd.Engine(search=search)
+        e.set_target(Q)
+        e.set_source(P[:6000] @ synth.rotation(0.01).T + 8.0 + np.array([0.02, -0.01, 0.015]))
+        hist = []
+        for _ in range(6):
+            e.iterate(1)
+            hist.append(e.get_last()["idx"].copy())
+        outs.append((hist, e.get_source()))
+        e.close()
+    for it in range(6):
+        assert np.array_equal(outs[0][0][it], outs[1][0][it]), it
+    assert np.array_equal(outs[0][1], outs[1][1])
+
+
+def test_processing_order_of_the_rows_changes_nothing(monkeypatch):
+    """The grid search takes the rows in a spatial order while the cloud moves and in storage order once it has settled
+    (ICP_AMD_GRID_ORDER_SWITCH, in cell half-edges of motion); rows that walk cells are re-packed inside their workgroup.
+    Always spatial (0), storage order from the second search on (1e30), the default and no spatial order at all must
+    agree on every iteration's indices and on the final cloud, bit for bit."""
+    P, Q = synth.make_pair(70000, 65000, seed=41, angle=0.2)
+    runs = []
+    for switch, order in (("0", "1"), ("1e30", "1"), (None, "1"), (None, "0")):
+        if switch is None:
+            monkeypatch.delenv("ICP_AMD_GRID_ORDER_SWITCH", raising=False)
+        else:
+            monkeypatch.setenv("ICP_AMD_GRID_ORDER_SWITCH", switch)
+        monkeypatch.setenv("ICP_AMD_GRID_ORDER", order)
+        e = icp_amd.Engine(search="grid")
+        e.set_target(Q)
+        e.set_source(P)
+        hist = []
+        for _ in range(12):
+            e.iterate(1)
+            hist.append(e.get_last()["idx"].copy())
+        runs.append((hist, e.get_source()))
+        e.close()
+    for r in runs[1:]:
+        for it in range(12):
+            assert np.array_equal(runs[0][0][it], r[0][it]), it
+        assert np.array_equal(runs[0][1], r[1])
