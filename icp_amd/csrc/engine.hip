@@ -148,6 +148,7 @@ struct icp_amd_engine {
     bool mfma16 = false;        // ... on the fp16 K = 16 MFMA (operands in two fp16 pieces), needs qrec16
     void *qrec16 = nullptr;     // 2 * m_pad 16-byte halves of the fp16 target records (built when that filter is selected)
     bool qrec16_ok = false;
+    bool qrec_ok = false;       // qrec / qmax / f32_ok describe the current target (built with it, or by the first brute-force launch)
     Grid grid;                  // uniform grid over Qz (search variant GRID); built on first use per target
     bool grid_built = false;
     uint32_t *order = nullptr;  // n_pad: source rows in spatial order (GRID), valid when order_ok
@@ -276,6 +277,25 @@ static int prepare_grid_source(icp_amd_engine *e);
 
 static const size_t kMaxRows = 0x7FFFFC00u;  // indices are 32-bit; padded sizes must fit too
 
+static bool wants_grid(const icp_amd_engine *e);
+static void choose_geometry(icp_amd_engine *e);
+
+// fp32 target records + range of the target, for the brute-force kernels; synchronises the stream (one 8-byte read-back)
+static int bruteforce_target(icp_amd_engine *e)
+{
+    if (e->qrec_ok) return ICP_AMD_OK;
+    HIPCHK(build_qrec(e->stream, e->Qz, e->m, e->m_pad, e->qrec, e->qmax2_dev));
+    unsigned long long bits = 0;
+    HIPCHK(hipMemcpyAsync(&bits, e->qmax2_dev, sizeof bits, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    double qmax2;
+    memcpy(&qmax2, &bits, sizeof qmax2);
+    e->f32_ok = (qmax2 == qmax2) && qmax2 > 1e-30 && qmax2 < 1e30;
+    e->qmax = e->f32_ok ? sqrt(qmax2) : 0.0;
+    e->qrec_ok = true;
+    return ICP_AMD_OK;
+}
+
 extern "C" int icp_amd_set_target(icp_amd_engine *e, const double *Q, size_t m)
 {
     if (!e || !Q) return fail(ICP_AMD_EINVAL, "icp_amd_set_target: NULL argument");
@@ -306,17 +326,17 @@ extern "C" int icp_amd_set_target(icp_amd_engine *e, const double *Q, size_t m)
     if (er == hipSuccess)
         er = aos_to_soa(e->stream, e->stage, m, m_pad, e->qc, std::numeric_limits<double>::infinity(), e->Qz);
     if (er == hipSuccess) er = build_rec(e->stream, e->Qz, m_pad);
-    if (er == hipSuccess) er = build_qrec(e->stream, e->Qz, m, m_pad, e->qrec, e->qmax2_dev);
-    unsigned long long bits = 0;
-    if (er == hipSuccess) er = hipMemcpyAsync(&bits, e->qmax2_dev, sizeof bits, hipMemcpyDeviceToHost, e->stream);
-    if (er == hipSuccess) er = hipStreamSynchronize(e->stream);
     (void)dfree_on(part, e->stream);
     HIPCHK(er);
-    double qmax2;
-    memcpy(&qmax2, &bits, sizeof qmax2);
-    e->f32_ok = (qmax2 == qmax2) && qmax2 > 1e-30 && qmax2 < 1e30;
-    e->qmax = e->f32_ok ? sqrt(qmax2) : 0.0;
+    // The brute-force kernels' own view of the target (fp32 records, the largest |q|, whether the fp32 bound means anything)
+    // is needed at once only where brute force is the search; behind the grid it is AUTO's rare fallback and is built by
+    // the first launch that needs it (bruteforce_target): 0.2 ms and a host synchronisation less per registration.
+    e->qrec_ok = false;
     e->qrec16_ok = false;
+    e->f32_ok = true;   // provisional until bruteforce_target() has seen the target's range
+    e->qmax = 0.0;
+    if (!wants_grid(e)) RCCHK(bruteforce_target(e));
+    else HIPCHK(hipStreamSynchronize(e->stream));   // the caller may reuse Q once this returns
     e->have_target = true;
     grid_free(&e->grid);
     e->grid_built = false;
@@ -605,6 +625,10 @@ extern "C" int icp_amd_step_search(icp_amd_engine *e)
                 *e->gscratch.host_mem = 0;
             }
             if (e->bf_left) { --e->bf_left; grid = false; }
+        }
+        if (!grid && !e->qrec_ok) {   // the first brute-force launch on a target that was set up for the grid
+            RCCHK(bruteforce_target(e));
+            choose_geometry(e);
         }
         // A brute-force launch without a previous correspondence (the first iteration of a run) re-learns every row's
         // running minimum ~ln(M) times on its exact path: 60 ms against 27 ms seeded at 1M x 1M.  Where a grid can be had,

@@ -65,6 +65,7 @@ __global__ __launch_bounds__(kWG) void grid_bbox_kernel(const double *__restrict
             hi[k] = b[k] > hi[k] ? b[k] : hi[k];
         }
     }
+    __shared__ unsigned long long s_lo[3][kWG / 64], s_hi[3][kWG / 64];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
 #pragma unroll
@@ -74,9 +75,22 @@ __global__ __launch_bounds__(kWG) void grid_bbox_kernel(const double *__restrict
             hi[k] = h2 > hi[k] ? h2 : hi[k];
         }
         if ((threadIdx.x & 63) == 0) {
-            atomicMin(&out[k], lo[k]);
-            atomicMax(&out[3 + k], hi[k]);
+            s_lo[k][threadIdx.x >> 6] = lo[k];
+            s_hi[k][threadIdx.x >> 6] = hi[k];
         }
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {   // six atomics per workgroup on the six result words (they serialise: 77 us with one set per wave)
+        const int k = threadIdx.x % 3;
+        const bool high = threadIdx.x >= 3;
+        unsigned long long v = high ? s_hi[k][0] : s_lo[k][0];
+#pragma unroll
+        for (int w = 1; w < kWG / 64; ++w) {
+            const unsigned long long o = high ? s_hi[k][w] : s_lo[k][w];
+            v = high ? (o > v ? o : v) : (o < v ? o : v);
+        }
+        if (high) atomicMax(&out[3 + k], v);
+        else atomicMin(&out[k], v);
     }
 }
 
@@ -763,7 +777,7 @@ static hipError_t grid_sort(hipStream_t s, Soa3 Qz, size_t m, double per_cell, b
     GRID_TRY(hipMemsetAsync(bb + 3, 0x00, 3 * sizeof(unsigned long long), s));
     {
         size_t blocks = (m + kWG - 1) / kWG;
-        if (blocks > 256) blocks = 256;   // every wave ends in six atomics on the same six words
+        if (blocks > 512) blocks = 512;   // every workgroup ends in six atomics on the same six words, and those serialise
         grid_bbox_kernel<<<(unsigned)blocks, kWG, 0, s>>>(Qz.x, Qz.y, Qz.z, m, bb);
     }
     GRID_TRY(hipGetLastError());
