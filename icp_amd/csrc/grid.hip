@@ -342,6 +342,7 @@ __global__ __launch_bounds__(kWG) void grid_occupied_kernel(const uint32_t *__re
     if ((threadIdx.x & 63) == 0 && mine) atomicAdd(out, mine);
 }
 
+template <int ROWS, int FLIGHT>   // rows of cells per group (their runs are walked as one sequence); record loads in flight per lane
 __global__ __launch_bounds__(kWG) void search_grid_kernel(const double *__restrict__ px, const double *__restrict__ py,
                                                           const double *__restrict__ pz, const double *__restrict__ pc, size_t n,
                                                           GridDesc g, const uint32_t *__restrict__ start,
@@ -514,9 +515,9 @@ __global__ __launch_bounds__(kWG) void search_grid_kernel(const double *__restri
         // this latency-bound kernel.  The visiting order changes nothing.
         int cy = b.cy0, cz = b.cz0;
         while (cz <= b.cz1 && !defer) {
-            uint32_t kb[4], ce[4], total = 0;
+            uint32_t kb[ROWS], ce[ROWS], total = 0;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < ROWS; ++u) {
                 uint32_t a0 = 0, a1 = 0;
                 if (cz <= b.cz1) {
                     const size_t row = ((size_t)cz * (size_t)g.dim[1] + (size_t)cy) * (size_t)g.dim[0];
@@ -537,22 +538,24 @@ __global__ __launch_bounds__(kWG) void search_grid_kernel(const double *__restri
                 }
             }
             // position t of the flattened sequence -> sorted position: t + (offset of the run that holds t); selects, no branches
-            const uint32_t o0 = kb[0], o1 = kb[1] - ce[0], o2 = kb[2] - ce[1], o3 = kb[3] - ce[2];
-            for (uint32_t t = 0; t < total; t += 4) {
-                double4 v[4];
-                uint32_t kk[4];
+            uint32_t o[ROWS];
+            o[0] = kb[0];
 #pragma unroll
-                for (int w = 0; w < 4; ++w) {
+            for (int u = 1; u < ROWS; ++u) o[u] = kb[u] - ce[u - 1];
+            for (uint32_t t = 0; t < total; t += FLIGHT) {
+                double4 v[FLIGHT];
+                uint32_t kk[FLIGHT];
+#pragma unroll
+                for (int w = 0; w < FLIGHT; ++w) {
                     const uint32_t tt = (t + w < total) ? t + w : t;   // past the end: a record that is met anyway (masked below)
-                    uint32_t off = o3;
-                    off = tt < ce[2] ? o2 : off;
-                    off = tt < ce[1] ? o1 : off;
-                    off = tt < ce[0] ? o0 : off;
+                    uint32_t off = o[ROWS - 1];
+#pragma unroll
+                    for (int u = ROWS - 2; u >= 0; --u) off = tt < ce[u] ? o[u] : off;
                     kk[w] = tt + off;
                     v[w] = rec[kk[w]];
                 }
 #pragma unroll
-                for (int w = 0; w < 4; ++w) {
+                for (int w = 0; w < FLIGHT; ++w) {
                     const double dw = d2_exact(ax, ay, az, v[w].x, v[w].y, v[w].z);
                     const double d = (w == 0 || t + w < total) ? dw : INFINITY;
                     d2 = __builtin_fmin(d2, __builtin_fmax(d, d1));
@@ -905,11 +908,13 @@ hipError_t search_grid(hipStream_t s, Soa3 P, size_t n, const double *pc, const 
     const char *sw = getenv("ICP_AMD_GRID_ORDER_SWITCH");   // read per launch: tests flip it inside one process
     const double order_switch = sw ? atof(sw) : 0.125;
     uint32_t *cnt = sc ? sc->count2 + sc->parity : nullptr, *cnt_next = sc ? sc->count2 + (sc->parity ^ 1) : nullptr;
-    search_grid_kernel<<<(unsigned)((n + kWG - 1) / kWG), kWG, 0, s>>>(P.x, P.y, P.z, pc, n, g.d, g.start, g.rec, Qz.x, Qz.y, Qz.z,
-                                                                      Qz.rec, (unsigned)m, idx_prev, P.rec, order, row_cap,
-                                                                      (unsigned)eval_cap, sc ? sc->defer_always : 0, cnt,
-                                                                      sc ? sc->list : nullptr, out_rec, P.rec ? motion : nullptr, order_switch,
-                                                                      (sc && sc->stat) ? sc->stat + 2 * (sc->stat_slot++ % kStatSlots) : nullptr);
+    // Rows per group x loads in flight: 4 x 4.  Measured against 4 x 8, 8 x 4 and 8 x 8 (profiles/r2_v2_grid_shape_ab.txt): eight
+    // loads in flight are 9-12 % slower everywhere (registers: 4 or 3 waves per SIMD instead of 5, and more masked slots),
+    // eight rows per group are equal on volumes and 10 % faster only on the first searches of a 1M-point sheet.
+    search_grid_kernel<4, 4><<<(unsigned)((n + kWG - 1) / kWG), kWG, 0, s>>>(P.x, P.y, P.z, pc, n, g.d, g.start, g.rec,
+        Qz.x, Qz.y, Qz.z, Qz.rec, (unsigned)m, idx_prev, P.rec, order, row_cap, (unsigned)eval_cap, sc ? sc->defer_always :
+        0, cnt, sc ? sc->list : nullptr, out_rec, P.rec ? motion : nullptr, order_switch, (sc && sc->stat) ? sc->stat + 2 *
+        (sc->stat_slot++ % kStatSlots) : nullptr);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || !sc) return e;
     size_t wgs = n < 512 ? n : 512;   // two per CU walk the queue; an empty queue (the usual case) costs the launch only
