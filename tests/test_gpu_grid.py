@@ -193,6 +193,20 @@ def test_grid_overflow_queue_and_auto_fallback(monkeypatch):
         assert np.array_equal(outs[0][0], o[0]) and np.array_equal(outs[0][1], o[1])
     assert stats["f32"]["grid_launches"] == 0 and stats["grid"]["brute_force_launches"] == 0
     assert stats["auto"]["grid_launches"] >= 1 and stats["auto"]["brute_force_launches"] >= 1, stats
+    # the same at a scale where the fp32 filter's bound means nothing: behind the grid the brute-force kernels learn the
+    # target's range only at their first launch, and must then pick the fp64 filter
+    outs = []
+    for search in ("exact", "auto"):
+        e = icp_amd.Engine(search=search)
+        e.set_target(Ql * 1e20)
+        e.set_source(Pl * 1e20)
+        for _ in range(6):   # the fallback decision reads the queue length of a FINISHED search: let each one finish
+            e.iterate(1)
+            e.sync()
+        outs.append((e.get_last()["idx"], e.get_source(), e.grid_stats()))
+        e.close()
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    assert outs[1][2]["brute_force_launches"] >= 1, outs[1][2]
 
 
 def test_grid_state_follows_target_and_source_replacement():
