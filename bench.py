@@ -251,6 +251,13 @@ def bench_batch(args, rank, world, local_rank):
                    "registrations_per_sec": regs / cdt,
                    "sample": "%d whole registrations (%d x %d, %d iterations) of the same batch, one per host thread, %.1f s"
                              % (regs, n, n, args.batch_iters, cdt)}
+        batch_traffic = measured_traffic("batch_icp_kernel", n, n, world)
+        try:   # the PMC pass must also be of this batch size and iteration count
+            rec = json.load(open(os.path.join(ROOT, "icp_amd", "measured_traffic.json"))).get("batch_icp_kernel") or {}
+            if batch_traffic[0] and (rec.get("batch"), rec.get("iters")) != (args.batch, args.batch_iters):
+                batch_traffic = (None, "no PMC pass on this batch size / iteration count", None)
+        except (OSError, ValueError):
+            batch_traffic = (None, "no measured_traffic.json", None)
         print(json.dumps({
             "metric": "distance_evals_per_sec", "value": pairs * args.steps / dt, "unit": "distance evals/s",
             "registrations_per_sec": args.batch * args.steps / dt, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -263,7 +270,7 @@ def bench_batch(args, rank, world, local_rank):
                          # one launch reads both clouds once and writes the registered cloud, the solve record and the
                          # indices; everything else stays in LDS / registers.  Algorithmic bytes, not a counter reading.
                          "algorithmic_bytes": float(hi - lo) * (n * 24 * 2 + n * 24 + n * 4 + 28 * 8),
-                         "traffic": None,
+                         "traffic": batch_traffic[0], "traffic_source_commit": batch_traffic[2], "traffic_note": batch_traffic[1],
                          "note": "8 un-fused fp64 flops per pair against the un-fused fp64 VALU peak; the kernel's default form "
                                  "issues 7 fp64 instructions per pair (3 FMA), so frac can approach 8/7"},
             "cpu_baseline": cpu,
