@@ -476,6 +476,16 @@ def main():
                 "speedup_vs_brute_force": (dt / args.steps) / (g_dt / g_steps), "search_kernel_avg_ms": g_ms,
                 "search": g_geo, "stats": g_stats, "first_step_ms": gr["first_ms"],
                 "ms_per_step_by_10": gr["ms_per_step_by_10"],
+                # HBM roofline of the settled grid search (hipEvent average of search_grid_kernel over the timed launches):
+                # 96 algorithmic bytes per source row -- its 64-byte record in, the 32-byte result half out
+                "roofline": {"bound": "hbm", "kernel": "search_grid_kernel", "achieved": 96.0 * gr["n_local"] / (g_ms * 1e-3) / 1e9
+                             if g_ms > 0 else 0.0, "peak": 8000.0, "unit": "GB/s",
+                             "frac": 96.0 * gr["n_local"] / (g_ms * 1e-3) / 8e12 if g_ms > 0 else 0.0,
+                             "algorithmic_bytes_per_row": 96, "avg_launch_ms": g_ms, "traffic": None,
+                             "iteration_bytes_per_row": 248,
+                             "iteration_frac": 248.0 * gr["n_local"] / (g_dt / g_steps) / 8e12,
+                             "note": "`iteration_*`: all five kernels of a settled iteration (search 96 B per row, covariance "
+                                     "68, apply 84) against the whole step time"},
                 "first_steps": {"ms_per_step": early["dt"] / g_steps * 1e3, "iters_per_sec": g_steps / early["dt"], "steps": g_steps,
                                 "warmup_steps": max(args.warmup, 3), "ms_per_step_by_10": early["ms_per_step_by_10"],
                                 "search_kernel_avg_ms": early["avg_ms"]},
