@@ -148,6 +148,7 @@ struct icp_amd_engine {
     bool mfma16 = false;        // ... on the fp16 K = 16 MFMA (operands in two fp16 pieces), needs qrec16
     void *qrec16 = nullptr;     // 2 * m_pad 16-byte halves of the fp16 target records (built when that filter is selected)
     bool qrec16_ok = false;
+    bool fuse_centroid = true;  // grid search on a cloud of few chunks finishes the centroid itself (no finalize_centroid launch)
     bool qrec_ok = false;       // qrec / qmax / f32_ok describe the current target (built with it, or by the first brute-force launch)
     Grid grid;                  // uniform grid over Qz (search variant GRID); built on first use per target
     bool grid_built = false;
@@ -463,6 +464,7 @@ static int plan_search(icp_amd_engine *e)
     choose_geometry(e);
     e->seed_enabled = env_int("ICP_AMD_SEED", 1) != 0;
     e->grid_cert = env_int("ICP_AMD_GRID_CERT", 1) != 0;
+    e->fuse_centroid = env_int("ICP_AMD_GRID_FUSE_CENTROID", 1) != 0;
     // On the grid path the brute-force kernels are only AUTO's fallback: their scratch (12 bytes per source row and
     // target split, 0.4 GB at 1M x 1M) is then allocated by the first fallback launch instead of here.
     if (!e->use_grid) RCCHK(ensure_split_buffers(e));
@@ -604,15 +606,12 @@ extern "C" int icp_amd_step_search(icp_amd_engine *e)
     if (!e || !e->have_source) return fail(ICP_AMD_ESTATE, "icp_amd_step_search: no source cloud");
     if (!e->cen_ready) return fail(ICP_AMD_ESTATE, "icp_amd_step_search: centroid partials missing (step_begin / step_update first)");
     HIPCHK(set_device(e->opt.device));
-    // P_center = P_copy.mean(0) (src/cpu/icp.cpp:206): chunk partials of every rank, summed in index order
-    HIPCHK(finalize_centroid(e->stream, e->cen_part, e->total_chunks, (double)e->n_global, e->pc));
     double *cov_slot = e->cov_part + (size_t)e->opt.rank * e->cpr * kCovW;
+    // P_center = P_copy.mean(0) (src/cpu/icp.cpp:206): chunk partials of every rank, summed in index order -- by a launch of
+    // its own, or (grid search on a cloud of few chunks) by the search kernel itself
+    if (!e->n) HIPCHK(finalize_centroid(e->stream, e->cen_part, e->total_chunks, (double)e->n_global, e->pc));
     if (e->n) {
         hipEvent_t a = nullptr, b = nullptr;
-        if (e->opt.kernel_timing) {
-            if (e->ev_used >= 4096) RCCHK(drain_events(e));
-            RCCHK(time_begin(e, &a, &b));
-        }
         const bool seed = e->have_prev && e->seed_enabled;
         bool grid = e->use_grid && e->gscratch.list && e->grid_out;
         if (grid && e->grid_auto) {
@@ -629,6 +628,12 @@ extern "C" int icp_amd_step_search(icp_amd_engine *e)
         if (!grid && !e->qrec_ok) {   // the first brute-force launch on a target that was set up for the grid
             RCCHK(bruteforce_target(e));
             choose_geometry(e);
+        }
+        const bool fuse_centroid = grid && e->fuse_centroid && e->total_chunks <= kGridFuseCentroidChunks;
+        if (!fuse_centroid) HIPCHK(finalize_centroid(e->stream, e->cen_part, e->total_chunks, (double)e->n_global, e->pc));
+        if (e->opt.kernel_timing) {
+            if (e->ev_used >= 4096) RCCHK(drain_events(e));
+            RCCHK(time_begin(e, &a, &b));
         }
         // A brute-force launch without a previous correspondence (the first iteration of a run) re-learns every row's
         // running minimum ~ln(M) times on its exact path: 60 ms against 27 ms seeded at 1M x 1M.  Where a grid can be had,
@@ -666,7 +671,8 @@ extern "C" int icp_amd_step_search(icp_amd_engine *e)
             // e->rec describes the motion since the previous search only if exactly one update ran in between
             HIPCHK(search_grid(e->stream, e->P, e->n, e->pc, e->grid, e->Qz, e->m, seed ? e->idx : nullptr,
                                e->order_ok ? e->order : nullptr, &e->gscratch, e->grid_out,
-                               (seed && e->updates_since_search == 1 && e->grid_cert) ? e->rec : nullptr));
+                               (seed && e->updates_since_search == 1 && e->grid_cert) ? e->rec : nullptr,
+                               fuse_centroid ? e->cen_part : nullptr, e->total_chunks, (double)e->n_global));
         } else if (e->variant == kF32 && e->mfma16) {
             if (!e->qrec16_ok) {   // the fp16 records of this target, on first use
                 if (!e->qrec16) HIPCHK(dmalloc(&e->qrec16, 32 * e->m_pad));

@@ -21,6 +21,7 @@
 // minimum goes through the lexicographic (key, index) comparison -- a total order, independent of visiting order.
 // One lane per source point; the previous iteration's correspondence (seed) makes the first box the final one.
 #include "kernels.h"
+#include "reduce.h"
 #include "exact.h"
 
 #include <math.h>
@@ -344,7 +345,7 @@ __global__ __launch_bounds__(kWG) void grid_occupied_kernel(const uint32_t *__re
 
 template <int ROWS, int FLIGHT>   // rows of cells per group (their runs are walked as one sequence); record loads in flight per lane
 __global__ __launch_bounds__(kWG) void search_grid_kernel(const double *__restrict__ px, const double *__restrict__ py,
-                                                          const double *__restrict__ pz, const double *__restrict__ pc, size_t n,
+                                                          const double *__restrict__ pz, double *__restrict__ pc_io, size_t n,
                                                           GridDesc g, const uint32_t *__restrict__ start,
                                                           const double4 *__restrict__ rec,
                                                           const double *__restrict__ qx, const double *__restrict__ qy,
@@ -356,9 +357,28 @@ __global__ __launch_bounds__(kWG) void search_grid_kernel(const double *__restri
                                                           uint32_t *__restrict__ ovf_count,
                                                           uint32_t *__restrict__ ovf_list, double2 *__restrict__ out_rec,
                                                           const double *__restrict__ mot, double order_switch,
-                                                          unsigned long long *__restrict__ stat)
+                                                          unsigned long long *__restrict__ stat,
+                                                          const double *__restrict__ cen_part, unsigned cen_chunks, double cen_denom)
 {
     const size_t l = (size_t)blockIdx.x * kWG + threadIdx.x;
+    // The source centroid: read from pc_io, or (cen_part != nullptr, small clouds) finished here by every workgroup for
+    // itself -- the fixed-order sum of the chunk partials that finalize_centroid_kernel would run as a launch of its own
+    // (3.7 us of a 30 us iteration); identical code on identical inputs, so every workgroup holds the same bits, and
+    // workgroup 0 publishes them for the kernels that follow.
+    double pc[3];
+    if (cen_part) {
+        __shared__ double s_stage[kWG];
+        __shared__ double s_pc[3];
+        const double acc = ordered_sum<kCenW, kWG>(cen_part, cen_chunks, s_stage);
+        if (threadIdx.x < 3) {
+            s_pc[threadIdx.x] = acc / cen_denom;
+            if (blockIdx.x == 0) pc_io[threadIdx.x] = acc / cen_denom;
+        }
+        __syncthreads();
+        pc[0] = s_pc[0]; pc[1] = s_pc[1]; pc[2] = s_pc[2];
+    } else {
+        pc[0] = pc_io[0]; pc[1] = pc_io[1]; pc[2] = pc_io[2];
+    }
     // order: source rows sorted by position, so that the lanes of a wave walk the same few cells (cache lines shared).
     // The rows themselves stay where they are, so everything a lane needs of its row comes from one 64-byte record
     // when the caller keeps one (prec: {x, y, z, previous index}, {that target's coordinates}).
@@ -898,8 +918,9 @@ hipError_t grid_order(hipStream_t s, Soa3 P, size_t n, uint32_t *order)
 }
 
 constexpr unsigned kStatSlots = 4096;
-hipError_t search_grid(hipStream_t s, Soa3 P, size_t n, const double *pc, const Grid &g, Soa3 Qz, size_t m,
-                       const uint32_t *idx_prev, const uint32_t *order, GridScratch *sc, double2 *out_rec, const double *motion)
+hipError_t search_grid(hipStream_t s, Soa3 P, size_t n, double *pc, const Grid &g, Soa3 Qz, size_t m,
+                       const uint32_t *idx_prev, const uint32_t *order, GridScratch *sc, double2 *out_rec, const double *motion,
+                       const double *cen_part, size_t cen_chunks, double cen_denom)
 {
     if (!g.ok || m == 0 || m > 0xFFFFFFF0u) return hipErrorInvalidValue;
     if (n == 0) return hipSuccess;
@@ -914,7 +935,7 @@ hipError_t search_grid(hipStream_t s, Soa3 P, size_t n, const double *pc, const 
     search_grid_kernel<4, 4><<<(unsigned)((n + kWG - 1) / kWG), kWG, 0, s>>>(P.x, P.y, P.z, pc, n, g.d, g.start, g.rec,
         Qz.x, Qz.y, Qz.z, Qz.rec, (unsigned)m, idx_prev, P.rec, order, row_cap, (unsigned)eval_cap, sc ? sc->defer_always :
         0, cnt, sc ? sc->list : nullptr, out_rec, P.rec ? motion : nullptr, order_switch, (sc && sc->stat) ? sc->stat + 2 *
-        (sc->stat_slot++ % kStatSlots) : nullptr);
+        (sc->stat_slot++ % kStatSlots) : nullptr, cen_part, (unsigned)cen_chunks, cen_denom);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || !sc) return e;
     size_t wgs = n < 512 ? n : 512;   // two per CU walk the queue; an empty queue (the usual case) costs the launch only

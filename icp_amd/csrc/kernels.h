@@ -133,9 +133,14 @@ void grid_scratch_free(GridScratch *sc);
 // source rows from their position at the previous search to the present one, pc being the centroid of the moved cloud.
 // With it a row whose previous search left a certificate wide enough for that motion keeps its match without visiting a
 // cell (grid.hip); nullptr = every row is searched.
-hipError_t search_grid(hipStream_t s, Soa3 P, size_t n, const double *pc, const Grid &g, Soa3 Qz, size_t m,
+// cen_part != nullptr: pc is an OUTPUT -- the launch finishes the centroid itself from cen_chunks chunk partials
+// (pc = fixed-order sum / cen_denom, the result of finalize_centroid) and workgroup 0 stores it in pc for the kernels that
+// follow; meant for clouds of up to kGridFuseCentroidChunks chunks, where that saves a launch for a 3 KB re-read per workgroup.
+constexpr size_t kGridFuseCentroidChunks = 128;
+hipError_t search_grid(hipStream_t s, Soa3 P, size_t n, double *pc, const Grid &g, Soa3 Qz, size_t m,
                        const uint32_t *idx_prev, const uint32_t *order, GridScratch *sc, double2 *out_rec,
-                       const double *motion = nullptr);
+                       const double *motion = nullptr, const double *cen_part = nullptr, size_t cen_chunks = 0,
+                       double cen_denom = 1.0);
 // P.rec[2i] = {x, y, z, "no index"}, P.rec[2i+1] = 0 for i < rows
 hipError_t build_source_rec(hipStream_t s, Soa3 P, size_t rows);
 hipError_t grid_order(hipStream_t s, Soa3 P, size_t n, uint32_t *order);

@@ -13,6 +13,7 @@
 // followed by an in-index-order sum over chunks, so results do not depend on the grid, on the number of
 // target splits, or on how many GPUs share the source rows.
 #include "kernels.h"
+#include "reduce.h"
 #include "exact.h"
 #include "search_common.h"
 
@@ -49,49 +50,6 @@ __device__ __forceinline__ double block_sum(double (&v)[NV], double *smem)
         tot = ((smem[0 * NV + k] + smem[1 * NV + k]) + smem[2 * NV + k]) + smem[3 * NV + k];
     }
     return tot;
-}
-
-// Fixed-order sum of `count` partial records of W doubles; thread k < W ends with the total of column k.
-// Order (independent of the launch geometry and of how the records were distributed over GPUs): groups of kSumGroup
-// consecutive records are summed in index order, then the group sums are summed in index order.  Up to kSumGroup
-// records that is the plain in-order sum.  The groups of one pass are summed by different threads at the same time, so
-// the dependent add chain is kSumGroup + count / kSumGroup long instead of count.
-constexpr int kSumGroup = 32;
-template <int W, int TB>   // TB = threads of the workgroup; stage holds TB doubles
-__device__ __forceinline__ double ordered_sum(const double *__restrict__ partial, size_t count, double *stage)
-{
-    constexpr int GP = TB / W;   // groups per pass
-    const int col = threadIdx.x % W, gl = threadIdx.x / W;
-    const size_t groups = (count + kSumGroup - 1) / kSumGroup;
-    double acc = 0.0;
-    for (size_t g0 = 0; g0 < groups; g0 += GP) {
-        double s = 0.0;
-        const size_t g = g0 + (size_t)gl;
-        if (gl < GP && g < groups) {
-            const size_t r0 = g * kSumGroup;
-            const int recs = (int)((count - r0 < (size_t)kSumGroup) ? (count - r0) : (size_t)kSumGroup);
-            const double *src = partial + r0 * W + col;
-            if (recs == kSumGroup) {   // every load of the group in flight before the first add: one memory latency, not four
-                double v[kSumGroup];
-#pragma unroll
-                for (int r = 0; r < kSumGroup; ++r) v[r] = src[(size_t)r * W];
-#pragma unroll
-                for (int r = 0; r < kSumGroup; ++r) s += v[r];
-            } else {
-#pragma unroll 8
-                for (int r = 0; r < recs; ++r) s += src[(size_t)r * W];
-            }
-        }
-        __syncthreads();
-        if (gl < GP) stage[gl * W + col] = s;
-        __syncthreads();
-        if (threadIdx.x < W) {
-            const int ng = (int)((groups - g0 < (size_t)GP) ? (groups - g0) : (size_t)GP);
-#pragma unroll 8
-            for (int k = 0; k < ng; ++k) acc += stage[k * W + threadIdx.x];
-        }
-    }
-    return acc;
 }
 
 __global__ __launch_bounds__(kWG) void colsum_partials_kernel(const double *__restrict__ aos, const double *__restrict__ x,
