@@ -8,13 +8,13 @@ LIB      := icp_amd/libicp_amd.so
 
 all: $(LIB) bin/GPUICP oracle
 
-$(CSRC)/kernels.o: $(CSRC)/kernels.hip $(CSRC)/kernels.h $(CSRC)/exact.h $(CSRC)/search_common.h
+$(CSRC)/kernels.o: $(CSRC)/kernels.hip $(CSRC)/kernels.h $(CSRC)/reduce.h $(CSRC)/exact.h $(CSRC)/search_common.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
 $(CSRC)/search_mfma.o: $(CSRC)/search_mfma.hip $(CSRC)/kernels.h $(CSRC)/exact.h $(CSRC)/search_common.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
-$(CSRC)/grid.o: $(CSRC)/grid.hip $(CSRC)/kernels.h $(CSRC)/exact.h
+$(CSRC)/grid.o: $(CSRC)/grid.hip $(CSRC)/kernels.h $(CSRC)/reduce.h $(CSRC)/exact.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
 $(CSRC)/devmem.o: $(CSRC)/devmem.cpp $(CSRC)/kernels.h
