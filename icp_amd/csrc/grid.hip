@@ -329,9 +329,6 @@ __device__ __forceinline__ double pack_idx_cert(uint32_t j, float cert)
     return __longlong_as_double((long long)(((unsigned long long)__float_as_uint(cert) << 32) | (unsigned long long)j));
 }
 
-// One lane per source point.  A lane whose box is large (more than row_cap rows of cells or eval_cap targets -- an
-// outlier far from every target, or an un-seeded first pass) does not walk it alone while the other 63 lanes of its
-// wave wait: it records what it has found so far and queues the point for search_grid_overflow_kernel.
 // number of non-empty cells (added to *out)
 __global__ __launch_bounds__(kWG) void grid_occupied_kernel(const uint32_t *__restrict__ counts, size_t cells,
                                                             unsigned long long *__restrict__ out)
@@ -343,6 +340,9 @@ __global__ __launch_bounds__(kWG) void grid_occupied_kernel(const uint32_t *__re
     if ((threadIdx.x & 63) == 0 && mine) atomicAdd(out, mine);
 }
 
+// One lane per source point.  A lane whose box is large (more than row_cap rows of cells or eval_cap targets -- an
+// outlier far from every target, or an un-seeded first pass) does not walk it alone while the other 63 lanes of its
+// wave wait: it records what it has found so far and queues the point for search_grid_overflow_kernel.
 template <int ROWS, int FLIGHT>   // rows of cells per group (their runs are walked as one sequence); record loads in flight per lane
 __global__ __launch_bounds__(kWG) void search_grid_kernel(const double *__restrict__ px, const double *__restrict__ py,
                                                           const double *__restrict__ pz, double *__restrict__ pc_io, size_t n,
