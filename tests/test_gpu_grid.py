@@ -373,16 +373,18 @@ def test_bound_from_the_visited_cells_with_targets_on_cell_edges(monkeypatch):
 def test_processing_order_of_the_rows_changes_nothing(monkeypatch):
     """The grid search takes the rows in a spatial order while the cloud moves and in storage order once it has settled
     (ICP_AMD_GRID_ORDER_SWITCH, in cell half-edges of motion); rows that walk cells are re-packed inside their workgroup.
-    Always spatial (0), storage order from the second search on (1e30), the default and no spatial order at all must
-    agree on every iteration's indices and on the final cloud, bit for bit."""
+    Always spatial (0), storage order from the second search on (1e30), the default, no spatial order at all, and the
+    centroid finished by its own launch instead of by the search must agree on every iteration's indices and on the final
+    cloud, bit for bit."""
     P, Q = synth.make_pair(70000, 65000, seed=41, angle=0.2)
     runs = []
-    for switch, order in (("0", "1"), ("1e30", "1"), (None, "1"), (None, "0")):
+    for switch, order, fuse in (("0", "1", "1"), ("1e30", "1", "1"), (None, "1", "1"), (None, "0", "1"), (None, "1", "0")):
         if switch is None:
             monkeypatch.delenv("ICP_AMD_GRID_ORDER_SWITCH", raising=False)
         else:
             monkeypatch.setenv("ICP_AMD_GRID_ORDER_SWITCH", switch)
         monkeypatch.setenv("ICP_AMD_GRID_ORDER", order)
+        monkeypatch.setenv("ICP_AMD_GRID_FUSE_CENTROID", fuse)   # 70 chunks: the search finishes the centroid itself, or not
         e = icp_amd.Engine(search="grid")
         e.set_target(Q)
         e.set_source(P)
