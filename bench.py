@@ -196,9 +196,11 @@ def cpu_reference(P, Q, rows=4000, targets=20000):
         return {"error": repr(exc)[:200], "kind": "reference"}
 
 
-def bench_batch(args, rank, world, local_rank):
-    """BASELINE configs[4]: 4096 independent registrations of 1k x 1k points, 20 iterations each, split evenly over
-    the GPUs with no data-path collective (weak scaling is not meaningful: total work is fixed)."""
+def measure_batch(args, rank, world, local_rank, steps, warmup, with_cpu):
+    """BASELINE configs[4]: args.batch independent registrations of n x n points, args.batch_iters iterations each, split
+    evenly over the GPUs with no data-path collective.  One step = one launch of batch_icp_kernel over this rank's share.
+    Returns the report (rank 0; None elsewhere).  The reference has no such mode: its `-batch` strip-mines ONE registration
+    16 source rows at a time (src/libgpuicp/batchcovs.cu:28-75)."""
     import torch
     import icp_amd
     from icp_amd import synth
@@ -210,83 +212,100 @@ def bench_batch(args, rank, world, local_rank):
     P, Q = np.tile(P, (reps, 1, 1))[:hi - lo], np.tile(Q, (reps, 1, 1))[:hi - lo]
     b = icp_amd.Batch(hi - lo, n, n, device=local_rank)
     b.upload(P, Q)
+    have_pg = False
+    if world > 1:
+        import torch.distributed as td
+        have_pg = td.is_initialized()
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
-            import torch.distributed as td
+        if have_pg:
             td.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         b.run(args.batch_iters)
     barrier()
     t0 = time.perf_counter()
     kms = 0.0
-    for _ in range(args.steps):
+    for _ in range(steps):
         kms += b.run(args.batch_iters, timed=True)
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
-        import torch.distributed as td
+    if have_pg:
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda" if td.get_backend() == "nccl" else "cpu")
         td.all_reduce(tmax, op=td.ReduceOp.MAX)
         dt = float(tmax.item())
-    if rank == 0:
-        pairs = float(args.batch) * n * n * args.batch_iters
-        ach = FLOPS_PER_PAIR * float(hi - lo) * n * n * args.batch_iters / (kms / args.steps * 1e-3)
-        cpu = None
-        if world == 1 and not args.no_cpu_baseline:
-            # the oracle port (the reference's loop, oracle/icp_oracle.c) on whole registrations of the same batch: each
-            # registration is independent, so the host cores take one each (OpenMP inside one 1k x 1k search does not pay)
-            from concurrent.futures import ThreadPoolExecutor
-            from oracle import pyoracle as orc
-            cores = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "0") or 0) or (os.cpu_count() or 1))
-            regs = max(64, 4 * cores)
-            t1 = time.perf_counter()
-            with ThreadPoolExecutor(cores) as ex:     # ctypes releases the GIL inside the C call
-                list(ex.map(lambda k: orc.icp(P[k % len(P)], Q[k % len(Q)], args.batch_iters, nthreads=1), range(regs)))
-            cdt = time.perf_counter() - t1
-            cpu = {"value": regs * float(n) * n * args.batch_iters / cdt, "unit": "distance evals/s", "cores": cores, "kind": "port",
-                   "registrations_per_sec": regs / cdt,
-                   "sample": "%d whole registrations (%d x %d, %d iterations) of the same batch, one per host thread, %.1f s"
-                             % (regs, n, n, args.batch_iters, cdt)}
-        batch_traffic = measured_traffic("batch_icp_kernel", n, n, world)
-        try:   # the PMC pass must also be of this batch size and iteration count
-            rec = json.load(open(os.path.join(ROOT, "icp_amd", "measured_traffic.json"))).get("batch_icp_kernel") or {}
-            if batch_traffic[0] and (rec.get("batch"), rec.get("iters")) != (args.batch, args.batch_iters):
-                batch_traffic = (None, "no PMC pass on this batch size / iteration count", None)
-        except (OSError, ValueError):
-            batch_traffic = (None, "no measured_traffic.json", None)
-        print(json.dumps({
-            "metric": "distance_evals_per_sec", "value": pairs * args.steps / dt, "unit": "distance evals/s",
-            "registrations_per_sec": args.batch * args.steps / dt, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[4]: %d registrations of %d x %d points, %d iterations each, %d per GPU"
-                                   % (args.batch, n, n, args.batch_iters, hi - lo), "parallelism": "batch-split%d" % world},
-            "roofline": {"bound": "valu_fp64", "kernel": "batch_icp_kernel", "achieved": ach / 1e12, "peak": PEAK_FP64_VALU_NOFMA / 1e12,
-                         "unit": "TFLOP/s", "frac": ach / PEAK_FP64_VALU_NOFMA, "avg_launch_ms": kms / args.steps,
-                         # one launch reads both clouds once and writes the registered cloud, the solve record and the
-                         # indices; everything else stays in LDS / registers.  Algorithmic bytes, not a counter reading.
-                         "algorithmic_bytes": float(hi - lo) * (n * 24 * 2 + n * 24 + n * 4 + 28 * 8),
-                         "traffic": batch_traffic[0], "traffic_source_commit": batch_traffic[2], "traffic_note": batch_traffic[1],
-                         "note": "8 un-fused fp64 flops per pair against the un-fused fp64 VALU peak; the kernel's default form "
-                                 "issues 7 fp64 instructions per pair (3 FMA), so frac can approach 8/7"},
-            "cpu_baseline": cpu,
-            "gpu_over_cpu": (pairs * args.steps / dt) / cpu["value"] if cpu else None}),
-            flush=True)
     b.close()
-    if world > 1:
-        import torch.distributed as td
+    if rank != 0:
+        return None
+    pairs = float(args.batch) * n * n * args.batch_iters
+    ach = FLOPS_PER_PAIR * float(hi - lo) * n * n * args.batch_iters / (kms / steps * 1e-3)
+    cpu = None
+    if with_cpu:
+        # the oracle port (the reference's loop, oracle/icp_oracle.c) on whole registrations of the same batch: each
+        # registration is independent, so the host cores take one each (OpenMP inside one 1k x 1k search does not pay)
+        from concurrent.futures import ThreadPoolExecutor
+        from oracle import pyoracle as orc
+        cores = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "0") or 0) or (os.cpu_count() or 1))
+        regs = max(64, 4 * cores)
+        t1 = time.perf_counter()
+        with ThreadPoolExecutor(cores) as ex:     # ctypes releases the GIL inside the C call
+            list(ex.map(lambda k: orc.icp(P[k % len(P)], Q[k % len(Q)], args.batch_iters, nthreads=1), range(regs)))
+        cdt = time.perf_counter() - t1
+        cpu = {"value": regs * float(n) * n * args.batch_iters / cdt, "unit": "distance evals/s", "cores": cores, "kind": "port",
+               "registrations_per_sec": regs / cdt,
+               "sample": "%d whole registrations (%d x %d, %d iterations) of the same batch, one per host thread, %.1f s"
+                         % (regs, n, n, args.batch_iters, cdt)}
+    batch_traffic = measured_traffic("batch_icp_kernel", n, n, world)
+    try:   # the PMC pass must also be of this batch size and iteration count
+        rec = json.load(open(os.path.join(ROOT, "icp_amd", "measured_traffic.json"))).get("batch_icp_kernel") or {}
+        if batch_traffic[0] and (rec.get("batch"), rec.get("iters")) != (args.batch, args.batch_iters):
+            batch_traffic = (None, "no PMC pass on this batch size / iteration count", None)
+    except (OSError, ValueError):
+        batch_traffic = (None, "no measured_traffic.json", None)
+    return {
+        "metric": "distance_evals_per_sec", "value": pairs * steps / dt, "unit": "distance evals/s",
+        "registrations_per_sec": args.batch * steps / dt, "n_gpus": world, "steps": steps, "warmup": warmup,
+        "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[4]: %d registrations of %d x %d points, %d iterations each, %d per GPU"
+                               % (args.batch, n, n, args.batch_iters, hi - lo), "parallelism": "batch-split%d" % world},
+        "roofline": {"bound": "valu_fp64", "kernel": "batch_icp_kernel", "achieved": ach / 1e12, "peak": PEAK_FP64_VALU_NOFMA / 1e12,
+                     "unit": "TFLOP/s", "frac": ach / PEAK_FP64_VALU_NOFMA, "avg_launch_ms": kms / steps,
+                     # one launch reads both clouds once and writes the registered cloud, the solve record and the
+                     # indices; everything else stays in LDS / registers.  Algorithmic bytes, not a counter reading.
+                     "algorithmic_bytes": float(hi - lo) * (n * 24 * 2 + n * 24 + n * 4 + 28 * 8),
+                     "traffic": batch_traffic[0], "traffic_source_commit": batch_traffic[2], "traffic_note": batch_traffic[1],
+                     "note": "8 un-fused fp64 flops per pair against the un-fused fp64 VALU peak; the kernel's default form "
+                             "issues 7 fp64 instructions per pair (3 FMA), so frac can approach 8/7"},
+        "cpu_baseline": cpu,
+        "gpu_over_cpu": (pairs * steps / dt) / cpu["value"] if cpu else None,
+        "reference_semantics": "no counterpart: the reference's -batch flag strip-mines ONE registration 16 source rows at a "
+                               "time (src/libgpuicp/batchcovs.cu:28-75); here a batch is thousands of independent registrations, "
+                               "one workgroup each, every one bit-identical to icp_amd_run on the same pair"}
+
+
+def bench_batch(args, rank, world, local_rank):
+    """`--workload batch`: BASELINE configs[4] as the whole JSON line (the default line carries it as `batch_mode`)."""
+    out = measure_batch(args, rank, world, local_rank, args.steps, args.warmup, world == 1 and not args.no_cpu_baseline)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    import torch.distributed as td
+    if td.is_available() and td.is_initialized():
         td.barrier()
         td.destroy_process_group()
 
 
 def launch_ranks(n):
-    """Runs this same command line under torch.distributed.run with `n` ranks on 127.0.0.1 and relays rank 0's JSON line."""
+    """Runs this same command line under torch.distributed.run with `n` ranks on 127.0.0.1 and relays rank 0's JSON line.
+    The child has a time limit of its own (ICP_AMD_BENCH_LAUNCH_TIMEOUT seconds, default 900): a rendezvous or an RCCL
+    initialisation that never completes ends with the child's process group killed, what it printed so far on stderr and a
+    non-zero exit, instead of running silently into whatever limit the caller has."""
+    import signal
     import socket
     import subprocess
+    import threading
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
@@ -294,14 +313,39 @@ def launch_ranks(n):
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
-    lines = []
-    for ln in proc.stdout:
-        if ln.startswith("{"):
-            lines.append(ln)
-        else:
-            sys.stderr.write(ln)
-    rc = proc.wait()
+    limit = float(os.environ.get("ICP_AMD_BENCH_LAUNCH_TIMEOUT", "900"))
+    # a fresh child in a session of its own (never a re-exec of this process), so that the whole tree can be signalled
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, start_new_session=True)
+    lines, seen = [], []
+
+    def relay():
+        for ln in proc.stdout:
+            if ln.startswith("{"):
+                lines.append(ln)
+            else:
+                seen.append(ln)
+                sys.stderr.write(ln)
+
+    reader = threading.Thread(target=relay, daemon=True)
+    reader.start()
+    try:
+        rc = proc.wait(timeout=limit)
+    except subprocess.TimeoutExpired:
+        for sig in (signal.SIGTERM, signal.SIGKILL):
+            try:
+                os.killpg(proc.pid, sig)
+            except ProcessLookupError:
+                break
+            try:
+                proc.wait(timeout=10)
+                break
+            except subprocess.TimeoutExpired:
+                continue
+        reader.join(timeout=5)
+        sys.stderr.write("bench.py: the %d-rank child did not finish within %.0f s and was killed; it had printed %d line(s)%s\n"
+                         % (n, limit, len(seen) + len(lines), (", the last: " + (lines + seen)[-1].strip()[:300]) if (lines or seen) else ""))
+        raise SystemExit(124)
+    reader.join(timeout=5)
     if lines:
         sys.stdout.write(lines[-1])
         sys.stdout.flush()
@@ -323,6 +367,7 @@ def main():
                     help="search variant of the headline measurement: f32 (default), fma, exact = brute force over all pairs")
     ap.add_argument("--no-grid", action="store_true", help="skip the extra grid-search measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-batch", action="store_true", help="skip the configs[4] measurement (`batch_mode`) of the default line")
     ap.add_argument("--no-fp64-variants", action="store_true", help="skip the extra fp64-only search variants at N=1")
     ap.add_argument("--workload", default="sharded", choices=["sharded", "batch"],
                     help="sharded: BASELINE configs[3] (default, the headline metric); batch: configs[4], 4096 x (1k x 1k)")
@@ -358,9 +403,21 @@ def main():
         local_rank = int(os.environ["ICP_AMD_BENCH_DEVICE"])
     backend = os.environ.get("ICP_AMD_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # ICP_AMD_BENCH_FORCE_PG=1 (one rank, no launcher): a one-rank RCCL process group is created anyway and the iteration's
+    # two all-gathers go through it, on the engine's stream, exactly as with eight ranks -- the one-GPU box's way of running
+    # the real exchange (tests/test_gpu_sharded.py)
+    force_pg = world == 1 and os.environ.get("ICP_AMD_BENCH_FORCE_PG", "0") == "1"
+    pg = world > 1 or force_pg          # a process group exists: the exchanges and the bench's own reductions use it
+    if pg:
         import torch.distributed as td
-        if backend == "nccl":
+        if force_pg:
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                port = sk.getsockname()[1]
+            td.init_process_group(backend, init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1,
+                                  **({"device_id": torch.device("cuda", local_rank)} if backend == "nccl" else {}))
+        elif backend == "nccl":
             td.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             td.init_process_group(backend)
@@ -373,13 +430,13 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if pg:
             td.barrier()
         torch.cuda.synchronize()
 
     def all_ranks(x):
-        """[x of rank 0, x of rank 1, ...] as floats (the value itself at world == 1)."""
-        if world == 1:
+        """[x of rank 0, x of rank 1, ...] as floats (the value itself without a process group)."""
+        if not pg:
             return [float(x)]
         buf = torch.zeros(world, dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         buf[rank] = float(x)
@@ -389,7 +446,8 @@ def main():
     def run(search, steps, warmup, repeats=0, extras=False, block_times=False):
         """`steps` timed iterations after `warmup` untimed ones.  Returns a dict: seconds (max over ranks), the search
         kernel's average launch ms (this rank's and every rank's), geometry, the last iteration's outputs, ..."""
-        runner = icpdist.ShardedIcp(P, Q, rank=rank, world=world, device=local_rank, search=search, kernel_timing=True)
+        runner = icpdist.ShardedIcp(P, Q, rank=rank, world=world, device=local_rank, search=search, kernel_timing=True,
+                                    force_collective=force_pg)
         runner.begin()
         first_ms = None
         for w in range(warmup):
@@ -427,7 +485,7 @@ def main():
             runner.step()
             barrier()
             step_samples.append((time.perf_counter() - t1) * 1e3)
-        if extras and world > 1:
+        if extras and pg:
             # the two exchanges of an iteration on their own (what the ranks wait for besides their kernels): `reps`
             # all-gathers of each buffer back to back on the runner's stream, bracketed like a step
             reps = 50
@@ -438,7 +496,7 @@ def main():
                 t1 = time.perf_counter()
                 with runner._on_stream():
                     for _ in range(reps):
-                        icpdist.exchange_partials(buf, width, rank, world)
+                        icpdist.exchange_partials(buf, width, rank, world, force=True)
                 barrier()
                 res["collective_ms"][name] = {"ms": max(all_ranks((time.perf_counter() - t1) * 1e3 / reps)), "bytes": buf.numel() * 8}
                 buf.copy_(keep)
@@ -494,6 +552,12 @@ def main():
                         "`ms_per_step` is taken once the registration has settled (after `warmup_steps` iterations); "
                         "`first_steps` is the same measurement at the start of the registration"}
 
+    # BASELINE configs[4] beside the headline (one warm-up + three launches of 4096 x (1k x 1k) x 20 iterations, ~0.1 s of GPU
+    # time; its CPU leg -- the oracle port on whole registrations, all cores -- a few seconds): `--no-batch` skips it
+    batch_mode = None
+    if not args.no_batch:
+        batch_mode = measure_batch(args, rank, world, local_rank, 3, 1, world == 1 and not args.no_cpu_baseline)
+
     if rank == 0:
         pairs = float(N) * float(M)
         evals_per_s = pairs * args.steps / dt
@@ -506,16 +570,22 @@ def main():
                                    % ("BASELINE configs[3]" if N == M == 1000000 else "BASELINE configs[2]" if N == M == 100000
                                       else "configs[3]-shaped workload at another size", N, M, world),
                        "n": N, "m": M, "parallelism": "p-shard%d" % world, "search": geo,
-                       "search_mode": "brute force: all N x M distances evaluated every iteration"},
+                       "search_mode": "brute force: all N x M distances evaluated every iteration",
+                       "scaling_note": "north_star's >= 6x from 1 to 8 GPUs applies to THIS path (brute force: 27 ms of search per "
+                                       "iteration at N = 1 against two latency-bound all-gathers); the grid search reported under "
+                                       "`grid_search` computes for ~40 us per iteration at 8 GPUs and is bound by those two "
+                                       "collectives, so sharding it buys little and no 6x is claimed for it"},
             # dominant kernel (the correspondence search, > 99 % of the step), from its own hipEvent-timed launches
             "roofline": roofline(geo["variant"], n_local, M, search_avg_ms, launches),
             "rms_last": last["rms"],
             "first_step_ms": head["first_ms"],
             "search_ms_per_rank": {"max": max(head["rank_ms"]), "min": min(head["rank_ms"]),
                                    "values": [round(v, 4) for v in head["rank_ms"]]},
-            "process_group": {"ranks": td.get_world_size() if world > 1 else 1,
-                              "backend": (("rccl (torch 'nccl')" if backend == "nccl" else backend) if world > 1 else "none")},
-            "rccl_ranks": (td.get_world_size() if (world > 1 and backend == "nccl") else (1 if world == 1 else 0)),
+            "process_group": {"ranks": td.get_world_size() if pg else 1,
+                              "backend": (("rccl (torch 'nccl')" if backend == "nccl" else backend) if pg else "none"),
+                              "forced_single_rank": bool(force_pg)},
+            # ranks of the RCCL communicator the iteration's all-gathers went through (0: no RCCL call was issued)
+            "rccl_ranks": (td.get_world_size() if (pg and backend == "nccl") else 0),
             "step_ms_samples": {"values": [round(v, 4) for v in step_samples], "median": float(np.median(step_samples)),
                                 "min": float(min(step_samples)),
                                 "note": "five more iterations after the timed region, each bracketed by its own barrier + "
@@ -542,6 +612,8 @@ def main():
             out["speedup_vs_n1"] = out["value"] / args.n1_value
         if grid:
             out["grid_search"] = grid
+        if batch_mode:
+            out["batch_mode"] = batch_mode
         if world == 1 and not args.no_fp64_variants:
             out["fp64_variants"] = fp64_variants(P, Q, local_rank)
             # the roofline SURVEY.md 8(d) defines: 8 un-fused fp64 flops per pair against the un-fused fp64 VALU peak, for the
@@ -556,7 +628,7 @@ def main():
             if ref:
                 out["cpu_reference"] = ref
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if pg:
         td.barrier()
         td.destroy_process_group()
 

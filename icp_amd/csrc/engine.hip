@@ -52,12 +52,11 @@ extern "C" int icp_amd_device_count(void)
     return n;
 }
 
-// hipGetLastError() is sticky per host thread and shared with every other HIP user of the process (torch, RCCL, an earlier
-// failed call): a stale error there would be reported by the next launch wrapper's `return hipGetLastError()` as if the
-// launch had failed.  Every entry point selects its device through this, which drops whatever was left behind first.
+// Every entry point selects its device through this.  It does NOT touch the host thread's sticky error word
+// (hipGetLastError), which belongs to every HIP user of the process: the launch wrappers take each launch's own return
+// code (kernels.h: launch()), so a stale error left by another library is neither mistaken for ours nor cleared.
 static hipError_t set_device(int device)
 {
-    (void)hipGetLastError();
     return hipSetDevice(device);
 }
 
@@ -462,6 +461,12 @@ static int plan_search(icp_amd_engine *e)
         e->grid_built = true;
     }
     choose_geometry(e);
+    if (!e->use_grid && !e->qrec_ok) {
+        // brute force is the planned search after all (a target the grid cannot file): f32_ok / qmax were provisional until
+        // now, and the geometry reported and the split buffers sized below must be those of the variant that will run
+        RCCHK(bruteforce_target(e));
+        choose_geometry(e);
+    }
     e->seed_enabled = env_int("ICP_AMD_SEED", 1) != 0;
     e->grid_cert = env_int("ICP_AMD_GRID_CERT", 1) != 0;
     e->fuse_centroid = env_int("ICP_AMD_GRID_FUSE_CENTROID", 1) != 0;
@@ -641,19 +646,33 @@ extern "C" int icp_amd_step_search(icp_amd_engine *e)
         // keeps the un-seeded launch (tests of that code path).
         bool grid_seeded = false;
         if (!grid && !seed && e->seed_enabled && e->m >= kAutoGridMinTargets && !e->P.rec && env_int("ICP_AMD_GRID_SEED", 1)) {
+            // Best effort: the seed only makes the launch below faster.  If the grid or its scratch cannot be had (e.g. out of
+            // memory beside the split buffers) the launch simply runs un-seeded; and an engine whose planned search is brute
+            // force gives the grid's memory back as soon as the seed is taken (one use per source cloud).
+            hipError_t ge = hipSuccess;
             if (!e->grid_built) {
-                HIPCHK(grid_build(e->stream, e->Qz, e->m, &e->grid));
-                e->grid_built = true;
+                ge = grid_build(e->stream, e->Qz, e->m, &e->grid);
+                e->grid_built = ge == hipSuccess;
             }
-            if (e->grid.ok) {
-                if (!e->gscratch.list) HIPCHK(grid_scratch_alloc(e->stream, e->n_pad, &e->gscratch));
-                if (!e->grid_out) HIPCHK(dmalloc(&e->grid_out, e->n_pad * sizeof(double2)));
-                e->gscratch.enabled = true;
-                HIPCHK(search_grid(e->stream, e->P, e->n, e->pc, e->grid, e->Qz, e->m, nullptr, nullptr, &e->gscratch, e->grid_out));
+            if (ge == hipSuccess && e->grid.ok) {
+                if (!e->gscratch.list) ge = grid_scratch_alloc(e->stream, e->n_pad, &e->gscratch);
+                if (ge == hipSuccess && !e->grid_out) ge = dmalloc(&e->grid_out, e->n_pad * sizeof(double2));
+                if (ge == hipSuccess) {
+                    e->gscratch.enabled = true;
+                    ge = search_grid(e->stream, e->P, e->n, e->pc, e->grid, e->Qz, e->m, nullptr, nullptr, &e->gscratch, e->grid_out);
+                }
                 // idx <- the grid's correspondences (the partial sums this also writes are overwritten below)
-                HIPCHK(merge_cov(e->stream, e->P, e->n, e->n_pad, e->pc, e->Qz, e->m, 1, nullptr, nullptr, e->grid_out, false, e->idx,
-                                 e->reject_d2, cov_slot));
-                grid_seeded = true;
+                if (ge == hipSuccess)
+                    ge = merge_cov(e->stream, e->P, e->n, e->n_pad, e->pc, e->Qz, e->m, 1, nullptr, nullptr, e->grid_out, false, e->idx,
+                                   e->reject_d2, cov_slot);
+                grid_seeded = ge == hipSuccess;
+            }
+            if (!wants_grid(e)) {   // explicit EXACT / FMA / F32 engine: nothing else will use these
+                grid_free(&e->grid);            // waits for the stream the grid was built and searched on
+                e->grid_built = false;
+                grid_scratch_free(&e->gscratch);
+                free_dev(e, e->grid_out);
+                e->grid_out = nullptr;
             }
         }
         const bool seeded = seed || grid_seeded;
@@ -1139,7 +1158,8 @@ extern "C" int icp_amd_run_multi(const double *P, size_t n, const double *Q, siz
         } else {
             int rc = g_rccl.GroupStart();
             for (int g = 0; g < G && rc == 0; ++g)
-                rc = g_rccl.Broadcast(r.eng[0]->rec + 12, chk[g], 12, Rccl::kDouble, 0, r.comm[g], r.eng[g]->stream);
+                // sendbuff is only read on the root; every rank still passes a pointer of its OWN device (pointer checks)
+                rc = g_rccl.Broadcast(g == 0 ? r.eng[0]->rec + 12 : chk[g], chk[g], 12, Rccl::kDouble, 0, r.comm[g], r.eng[g]->stream);
             const int rc2 = g_rccl.GroupEnd();
             if (rc == 0) rc = rc2;
             if (rc != 0) return fail(ICP_AMD_EHIP, "RCCL broadcast failed: %s", g_rccl.GetErrorString(rc));
@@ -1414,18 +1434,20 @@ static int correspondences_impl(const double *P, size_t n, const double Pc[3], c
     if (!grid && !prev && search_variant != ICP_AMD_SEARCH_GRID && m >= kAutoGridMinTargets && env_int("ICP_AMD_GRID_SEED", 1)) {
         // like the engine's first iteration: the grid's exact answer seeds the brute-force scan (which still evaluates
         // every pair); targets the grid cannot file (non-finite coordinates) leave the launch un-seeded
-        HIPCHK(grid_build(s, dQ, m, &gh.g));
-        if (gh.g.ok) {
+        // best effort, like the engine: a seed that cannot be had (no memory for the grid) leaves the launch un-seeded
+        hipError_t ge = grid_build(s, dQ, m, &gh.g);
+        if (ge == hipSuccess && gh.g.ok) {
             struct ScratchHolder { GridScratch sc; ~ScratchHolder() { grid_scratch_free(&sc); } } sh;
-            HIPCHK(grid_scratch_alloc(s, n, &sh.sc));
-            HIPCHK(grec.alloc(n_pad * sizeof(double2)));
-            HIPCHK(seeds.alloc(n_pad * sizeof(uint32_t)));
-            HIPCHK(hipMemsetAsync(seeds.p, 0xFF, n_pad * sizeof(uint32_t), s));
-            HIPCHK(search_grid(s, dP, n, pc.as<double>(), gh.g, dQ, m, nullptr, nullptr, &sh.sc, grec.as<double2>()));
-            HIPCHK(merge_cov(s, dP, n, n_pad, pc.as<double>(), dQ, m, 1, nullptr, nullptr, grec.as<double2>(), false, seeds.as<uint32_t>(),
-                             std::numeric_limits<double>::infinity(), part.as<double>()));
+            ge = grid_scratch_alloc(s, n, &sh.sc);
+            if (ge == hipSuccess) ge = grec.alloc(n_pad * sizeof(double2));
+            if (ge == hipSuccess) ge = seeds.alloc(n_pad * sizeof(uint32_t));
+            if (ge == hipSuccess) ge = hipMemsetAsync(seeds.p, 0xFF, n_pad * sizeof(uint32_t), s);
+            if (ge == hipSuccess) ge = search_grid(s, dP, n, pc.as<double>(), gh.g, dQ, m, nullptr, nullptr, &sh.sc, grec.as<double2>());
+            if (ge == hipSuccess)
+                ge = merge_cov(s, dP, n, n_pad, pc.as<double>(), dQ, m, 1, nullptr, nullptr, grec.as<double2>(), false, seeds.as<uint32_t>(),
+                               std::numeric_limits<double>::infinity(), part.as<double>());
             HIPCHK(hipStreamSynchronize(s));   // the scratch is released on scope exit
-            prev = seeds.as<uint32_t>();
+            if (ge == hipSuccess) prev = seeds.as<uint32_t>();
         }
     }
     if (grid) {

@@ -717,8 +717,7 @@ __global__ __launch_bounds__(kWG) void search_grid_overflow_kernel(
 __global__ void grid_warmup_kernel() {}
 hipError_t grid_warmup(hipStream_t s)
 {
-    grid_warmup_kernel<<<1, 64, 0, s>>>();
-    return hipGetLastError();
+    return launch(grid_warmup_kernel, dim3(1), dim3(64), 0, s);
 }
 
 void grid_free(Grid *g)
@@ -801,9 +800,8 @@ static hipError_t grid_sort(hipStream_t s, Soa3 Qz, size_t m, double per_cell, b
     {
         size_t blocks = (m + kWG - 1) / kWG;
         if (blocks > 512) blocks = 512;   // every workgroup ends in six atomics on the same six words, and those serialise
-        grid_bbox_kernel<<<(unsigned)blocks, kWG, 0, s>>>(Qz.x, Qz.y, Qz.z, m, bb);
+        GRID_TRY(launch(grid_bbox_kernel, dim3((unsigned)blocks), dim3(kWG), 0, s, Qz.x, Qz.y, Qz.z, m, bb));
     }
-    GRID_TRY(hipGetLastError());
     GRID_TRY(hipMemcpyAsync(host_bb, bb, sizeof host_bb, hipMemcpyDeviceToHost, s));
     GRID_TRY(hipStreamSynchronize(s));
     {
@@ -829,13 +827,11 @@ static hipError_t grid_sort(hipStream_t s, Soa3 Qz, size_t m, double per_cell, b
             g->cells = (size_t)g->d.dim[0] * (size_t)g->d.dim[1] * (size_t)g->d.dim[2];
             GRID_TRY(dmalloc(&counts, g->cells * sizeof(uint32_t)));
             GRID_TRY(hipMemsetAsync(counts, 0, g->cells * sizeof(uint32_t), s));
-            grid_count_kernel<<<(unsigned)((m + kWG - 1) / kWG), kWG, 0, s>>>(Qz.x, Qz.y, Qz.z, m, g->d, cell, counts);
-            GRID_TRY(hipGetLastError());
+            GRID_TRY(launch(grid_count_kernel, dim3((unsigned)((m + kWG - 1) / kWG)), dim3(kWG), 0, s, Qz.x, Qz.y, Qz.z, m, g->d, cell, counts));
             if (!refine || round == 3 || (double)g->cells > kMaxCells / 2.0) break;
             unsigned long long occupied = 0;
             GRID_TRY(hipMemsetAsync(bb, 0, sizeof(unsigned long long), s));
-            grid_occupied_kernel<<<256, kWG, 0, s>>>(counts, g->cells, bb);
-            GRID_TRY(hipGetLastError());
+            GRID_TRY(launch(grid_occupied_kernel, dim3(256), dim3(kWG), 0, s, counts, g->cells, bb));
             GRID_TRY(hipMemcpyAsync(&occupied, bb, sizeof occupied, hipMemcpyDeviceToHost, s));
             GRID_TRY(hipStreamSynchronize(s));
             const double avg = (double)m / (double)(occupied ? occupied : 1);
@@ -851,20 +847,16 @@ static hipError_t grid_sort(hipStream_t s, Soa3 Qz, size_t m, double per_cell, b
     if (with_coords) GRID_TRY(dmalloc(&g->rec, m * sizeof(double4)));
     GRID_TRY(dmalloc(&cursor, g->cells * sizeof(uint32_t)));
     if (g->cells <= 65536) {
-        grid_scan_kernel<<<1, 1024, 0, s>>>(counts, g->cells, g->start, cursor);
+        GRID_TRY(launch(grid_scan_kernel, dim3(1), dim3(1024), 0, s, counts, g->cells, g->start, cursor));
     } else {
         const size_t blocks = (g->cells + kScanPerBlock - 1) / kScanPerBlock;   // <= 4096
         GRID_TRY(dmalloc(&block_sums, 3 * (blocks + 1) * sizeof(uint32_t)));
         uint32_t *block_off = block_sums + blocks + 1, *unused_copy = block_off + blocks + 1;
-        grid_scan_sums_kernel<<<(unsigned)blocks, kWG, 0, s>>>(counts, g->cells, block_sums);
-        GRID_TRY(hipGetLastError());
-        grid_scan_kernel<<<1, 1024, 0, s>>>(block_sums, blocks, block_off, unused_copy);
-        GRID_TRY(hipGetLastError());
-        grid_scan_apply_kernel<<<(unsigned)blocks, kWG, 0, s>>>(counts, g->cells, block_off, g->start, cursor);
+        GRID_TRY(launch(grid_scan_sums_kernel, dim3((unsigned)blocks), dim3(kWG), 0, s, counts, g->cells, block_sums));
+        GRID_TRY(launch(grid_scan_kernel, dim3(1), dim3(1024), 0, s, block_sums, blocks, block_off, unused_copy));
+        GRID_TRY(launch(grid_scan_apply_kernel, dim3((unsigned)blocks), dim3(kWG), 0, s, counts, g->cells, block_off, g->start, cursor));
     }
-    GRID_TRY(hipGetLastError());
-    grid_scatter_kernel<<<(unsigned)((m + kWG - 1) / kWG), kWG, 0, s>>>(Qz.x, Qz.y, Qz.z, m, cell, cursor, g->rec, g->perm);
-    GRID_TRY(hipGetLastError());
+    GRID_TRY(launch(grid_scatter_kernel, dim3((unsigned)((m + kWG - 1) / kWG)), dim3(kWG), 0, s, Qz.x, Qz.y, Qz.z, m, cell, cursor, g->rec, g->perm));
     GRID_TRY(hipStreamSynchronize(s));   // the temporaries are freed below
     g->ok = true;
 #undef GRID_TRY
@@ -909,8 +901,7 @@ hipError_t grid_order(hipStream_t s, Soa3 P, size_t n, uint32_t *order)
     if (g.ok) {
         e = hipMemcpyAsync(order, g.perm, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, s);
     } else {
-        iota_kernel<<<(unsigned)((n + kWG - 1) / kWG), kWG, 0, s>>>(order, n);
-        e = hipGetLastError();
+        e = launch(iota_kernel, dim3((unsigned)((n + kWG - 1) / kWG)), dim3(kWG), 0, s, order, n);
     }
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     grid_free(&g);
@@ -924,25 +915,27 @@ hipError_t search_grid(hipStream_t s, Soa3 P, size_t n, double *pc, const Grid &
 {
     if (!g.ok || m == 0 || m > 0xFFFFFFF0u) return hipErrorInvalidValue;
     if (n == 0) return hipSuccess;
+    const double order_switch = sc ? sc->order_switch : 0.125;   // read from the environment once, when the scratch was allocated
+    if (sc && sc->stat && sc->stat_slot >= kStatSlots) {         // a diagnostics slot that is used again starts from zero
+        hipError_t ez = hipMemsetAsync(sc->stat + 2 * (sc->stat_slot % kStatSlots), 0, 2 * sizeof(unsigned long long), s);
+        if (ez != hipSuccess) return ez;
+    }
     if (sc && !sc->enabled) sc = nullptr;
     const int row_cap = sc ? sc->row_cap : 64, eval_cap = sc ? sc->eval_cap : 768;
-    const char *sw = getenv("ICP_AMD_GRID_ORDER_SWITCH");   // read per launch: tests flip it inside one process
-    const double order_switch = sw ? atof(sw) : 0.125;
     uint32_t *cnt = sc ? sc->count2 + sc->parity : nullptr, *cnt_next = sc ? sc->count2 + (sc->parity ^ 1) : nullptr;
     // Rows per group x loads in flight: 4 x 4.  Measured against 4 x 8, 8 x 4 and 8 x 8 (profiles/r2_v2_grid_shape_ab.txt): eight
     // loads in flight are 9-12 % slower everywhere (registers: 4 or 3 waves per SIMD instead of 5, and more masked slots),
     // eight rows per group are equal on volumes and 10 % faster only on the first searches of a 1M-point sheet.
-    search_grid_kernel<4, 4><<<(unsigned)((n + kWG - 1) / kWG), kWG, 0, s>>>(P.x, P.y, P.z, pc, n, g.d, g.start, g.rec,
+    hipError_t e = launch(search_grid_kernel<4, 4>, dim3((unsigned)((n + kWG - 1) / kWG)), dim3(kWG), 0, s, P.x, P.y, P.z, pc, n, g.d, g.start, g.rec,
         Qz.x, Qz.y, Qz.z, Qz.rec, (unsigned)m, idx_prev, P.rec, order, row_cap, (unsigned)eval_cap, sc ? sc->defer_always :
         0, cnt, sc ? sc->list : nullptr, out_rec, P.rec ? motion : nullptr, order_switch, (sc && sc->stat) ? sc->stat + 2 *
         (sc->stat_slot++ % kStatSlots) : nullptr, cen_part, (unsigned)cen_chunks, cen_denom);
-    hipError_t e = hipGetLastError();
     if (e != hipSuccess || !sc) return e;
     size_t wgs = n < 512 ? n : 512;   // two per CU walk the queue; an empty queue (the usual case) costs the launch only
-    search_grid_overflow_kernel<<<(unsigned)wgs, kWG, 0, s>>>(P.x, P.y, P.z, pc, g.d, g.start, g.rec, Qz.x, Qz.y, Qz.z, Qz.rec,
+    e = launch(search_grid_overflow_kernel, dim3((unsigned)wgs), dim3(kWG), 0, s, P.x, P.y, P.z, pc, g.d, g.start, g.rec, Qz.x, Qz.y, Qz.z, Qz.rec,
                                                              (unsigned)m, cnt, cnt_next, sc->list, sc->host_count, P.rec, out_rec);
     sc->parity ^= 1;
-    return hipGetLastError();
+    return e;
 }
 
 hipError_t grid_scratch_alloc(hipStream_t s, size_t n, GridScratch *sc)
@@ -952,6 +945,7 @@ hipError_t grid_scratch_alloc(hipStream_t s, size_t n, GridScratch *sc)
     sc->row_cap = getenv("ICP_AMD_GRID_ROWCAP") ? atoi(getenv("ICP_AMD_GRID_ROWCAP")) : 64;
     sc->eval_cap = getenv("ICP_AMD_GRID_EVALCAP") ? atoi(getenv("ICP_AMD_GRID_EVALCAP")) : 768;
     sc->defer_always = getenv("ICP_AMD_GRID_DEFER") && !strcmp(getenv("ICP_AMD_GRID_DEFER"), "always");
+    sc->order_switch = getenv("ICP_AMD_GRID_ORDER_SWITCH") ? atof(getenv("ICP_AMD_GRID_ORDER_SWITCH")) : 0.125;
     hipError_t e = dmalloc(&sc->count2, 2 * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMemsetAsync(sc->count2, 0, 2 * sizeof(uint32_t), s);   // s: the stream the searches will run on
     if (e == hipSuccess) e = dmalloc(&sc->list, (n ? n : 1) * sizeof(uint32_t));

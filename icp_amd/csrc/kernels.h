@@ -4,7 +4,29 @@
 #include <stdint.h>
 #include <stddef.h>
 
+#include <tuple>
+#include <utility>
+
 namespace icpk {
+
+// Launches `kernel` and returns THAT launch's status (what hipLaunchKernel itself returns).  `k<<<...>>>(...)` followed by
+// hipGetLastError() reports the host thread's sticky error word instead, which every HIP user of the process shares: a
+// stale error left there by another library (torch, RCCL) would be taken for a failed launch of ours, and clearing the
+// word before every call would swallow the host application's own errors.  This helper neither reads nor clears it.
+template <typename... KArgs, size_t... I>
+inline hipError_t launch_impl(void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t lds, hipStream_t s,
+                              std::tuple<KArgs...> &vals, std::index_sequence<I...>)
+{
+    void *ptrs[] = {(void *)&std::get<I>(vals)..., nullptr};
+    return hipLaunchKernel((const void *)kernel, grid, block, ptrs, lds, s);
+}
+template <typename... KArgs, typename... Args>
+inline hipError_t launch(void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t lds, hipStream_t s, Args... args)
+{
+    static_assert(sizeof...(KArgs) == sizeof...(Args), "launch(): argument count differs from the kernel's");
+    std::tuple<KArgs...> vals{static_cast<KArgs>(args)...};
+    return launch_impl(kernel, grid, block, lds, s, vals, std::index_sequence_for<KArgs...>{});
+}
 
 // Geometry shared by every kernel.
 constexpr int kWG      = 256;    // threads per workgroup (4 wave64)
@@ -116,6 +138,7 @@ struct GridScratch {
     int parity = 0;
     int row_cap = 64, eval_cap = 768;       // rows of cells / targets one lane walks alone (read from the environment at allocation)
     int defer_always = 0;                   // 1: hand over every box above the caps (tests); 0: only when most of the wave would idle
+    double order_switch = 0.125;            // motion (cell half-edges) below which rows are taken in storage order (ICP_AMD_GRID_ORDER_SWITCH)
     unsigned long long *stat = nullptr;     // ICP_AMD_GRID_STATS=1 (diagnostics): per launch {rows that walked cells, targets evaluated},
     unsigned stat_slot = 0;                 // printed to stderr when the scratch is released
     bool enabled = true;                    // false: this launch hands nothing over (every lane finishes its own point) and the

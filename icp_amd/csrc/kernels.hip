@@ -1076,21 +1076,18 @@ static inline unsigned blocks_for(size_t n, size_t per) { return (unsigned)((n +
 hipError_t colsum_partials(hipStream_t s, const double *aos, Soa3 soa, size_t n, double *partial)
 {
     if (n == 0) return hipSuccess;
-    colsum_partials_kernel<<<blocks_for(n, kChunk), kWG, 0, s>>>(aos, soa.x, soa.y, soa.z, n, partial);
-    return hipGetLastError();
+    return launch(colsum_partials_kernel, dim3(blocks_for(n, kChunk)), dim3(kWG), 0, s, aos, soa.x, soa.y, soa.z, n, partial);
 }
 
 hipError_t finalize_centroid(hipStream_t s, const double *partial, size_t count, double denom, double *out3)
 {
-    finalize_centroid_kernel<<<1, kWG, 0, s>>>(partial, count, denom, out3);
-    return hipGetLastError();
+    return launch(finalize_centroid_kernel, dim3(1), dim3(kWG), 0, s, partial, count, denom, out3);
 }
 
 hipError_t aos_to_soa(hipStream_t s, const double *aos, size_t n, size_t n_pad, const double *c3, double pad, Soa3 out)
 {
     if (n_pad == 0) return hipSuccess;
-    aos_to_soa_kernel<<<blocks_for(n_pad, kWG), kWG, 0, s>>>(aos, n, n_pad, c3, pad, out.x, out.y, out.z);
-    return hipGetLastError();
+    return launch(aos_to_soa_kernel, dim3(blocks_for(n_pad, kWG)), dim3(kWG), 0, s, aos, n, n_pad, c3, pad, out.x, out.y, out.z);
 }
 
 __global__ __launch_bounds__(kWG) void build_rec_kernel(const double *__restrict__ x, const double *__restrict__ y,
@@ -1103,8 +1100,7 @@ __global__ __launch_bounds__(kWG) void build_rec_kernel(const double *__restrict
 hipError_t build_rec(hipStream_t s, Soa3 soa, size_t rows)
 {
     if (rows == 0 || !soa.rec) return hipErrorInvalidValue;
-    build_rec_kernel<<<blocks_for(rows, kWG), kWG, 0, s>>>(soa.x, soa.y, soa.z, rows, soa.rec);
-    return hipGetLastError();
+    return launch(build_rec_kernel, dim3(blocks_for(rows, kWG)), dim3(kWG), 0, s, soa.x, soa.y, soa.z, rows, soa.rec);
 }
 
 __global__ __launch_bounds__(kWG) void build_source_rec_kernel(const double *__restrict__ x, const double *__restrict__ y,
@@ -1119,15 +1115,13 @@ __global__ __launch_bounds__(kWG) void build_source_rec_kernel(const double *__r
 hipError_t build_source_rec(hipStream_t s, Soa3 P, size_t rows)
 {
     if (rows == 0 || !P.rec) return hipErrorInvalidValue;
-    build_source_rec_kernel<<<blocks_for(rows, kWG), kWG, 0, s>>>(P.x, P.y, P.z, rows, P.rec);
-    return hipGetLastError();
+    return launch(build_source_rec_kernel, dim3(blocks_for(rows, kWG)), dim3(kWG), 0, s, P.x, P.y, P.z, rows, P.rec);
 }
 
 hipError_t soa_to_aos(hipStream_t s, Soa3 in, size_t n, double *aos)
 {
     if (n == 0) return hipSuccess;
-    soa_to_aos_kernel<<<blocks_for(n, kWG), kWG, 0, s>>>(in.x, in.y, in.z, n, aos);
-    return hipGetLastError();
+    return launch(soa_to_aos_kernel, dim3(blocks_for(n, kWG)), dim3(kWG), 0, s, in.x, in.y, in.z, n, aos);
 }
 
 // Split geometry shared by both search kernels: the scanned range is m rounded up to kSplitGran targets (pads inside
@@ -1147,12 +1141,10 @@ static hipError_t search_launch(hipStream_t s, int variant, Soa3 P, size_t n_pad
     const unsigned q_per_split = (unsigned)search_rows_per_split(m, q_splits);
     dim3 grid((unsigned)(n_pad / (kWG * PPL)), (unsigned)q_splits);
     if (variant == kFma)
-        search_kernel<PPL, kFma, CB><<<grid, kWG, 0, s>>>(P.x, P.y, P.z, pc, Qz.x, Qz.y, Qz.z, (unsigned)n_pad, (unsigned)m,
-                                                          m_scan, q_per_split, idx_prev, out_key, out_idx);
-    else
-        search_kernel<PPL, kExact, CB><<<grid, kWG, 0, s>>>(P.x, P.y, P.z, pc, Qz.x, Qz.y, Qz.z, (unsigned)n_pad, (unsigned)m,
-                                                            m_scan, q_per_split, idx_prev, out_key, out_idx);
-    return hipGetLastError();
+        return launch(search_kernel<PPL, kFma, CB>, grid, dim3(kWG), 0, s, P.x, P.y, P.z, pc, Qz.x, Qz.y, Qz.z, (unsigned)n_pad,
+                      (unsigned)m, m_scan, q_per_split, idx_prev, out_key, out_idx);
+    return launch(search_kernel<PPL, kExact, CB>, grid, dim3(kWG), 0, s, P.x, P.y, P.z, pc, Qz.x, Qz.y, Qz.z, (unsigned)n_pad,
+                  (unsigned)m, m_scan, q_per_split, idx_prev, out_key, out_idx);
 }
 
 hipError_t search(hipStream_t s, int variant, int ppl, int cb, Soa3 P, size_t n_pad, const double *pc, Soa3 Qz, size_t m,
@@ -1173,8 +1165,7 @@ hipError_t build_qrec(hipStream_t s, Soa3 Qz, size_t m, size_t m_pad, void *qrec
     if (m_pad == 0) return hipErrorInvalidValue;
     hipError_t e = hipMemsetAsync(qmax2_bits, 0, sizeof(unsigned long long), s);
     if (e != hipSuccess) return e;
-    build_qrec_kernel<<<blocks_for(m_pad, kWG), kWG, 0, s>>>(Qz.x, Qz.y, Qz.z, m, m_pad, (QRec *)qrec, qmax2_bits);
-    return hipGetLastError();
+    return launch(build_qrec_kernel, dim3(blocks_for(m_pad, kWG)), dim3(kWG), 0, s, Qz.x, Qz.y, Qz.z, m, m_pad, (QRec *)qrec, qmax2_bits);
 }
 
 template <int PPL, int CB, bool PK>
@@ -1184,9 +1175,8 @@ static hipError_t search_f32_launch(hipStream_t s, Soa3 P, size_t n_pad, const d
     const unsigned m_scan = (unsigned)search_scan_rows(m);
     const unsigned q_per_split = (unsigned)search_rows_per_split(m, q_splits);
     dim3 grid((unsigned)(n_pad / (kWG * PPL)), (unsigned)q_splits);
-    search_f32_kernel<PPL, CB, PK><<<grid, kWG, 0, s>>>(P.x, P.y, P.z, pc, Qz.x, Qz.y, Qz.z, (const QRec *)qrec, qmax, (unsigned)n_pad,
+    return launch(search_f32_kernel<PPL, CB, PK>, dim3(grid), dim3(kWG), 0, s, P.x, P.y, P.z, pc, Qz.x, Qz.y, Qz.z, (const QRec *)qrec, qmax, (unsigned)n_pad,
                                                     (unsigned)m, m_scan, q_per_split, idx_prev, out_key, out_idx);
-    return hipGetLastError();
 }
 
 hipError_t search_f32(hipStream_t s, int ppl, int cb, Soa3 P, size_t n_pad, const double *pc, Soa3 Qz, const void *qrec, double qmax,
@@ -1211,36 +1201,31 @@ hipError_t merge_cov(hipStream_t s, Soa3 P, size_t n, size_t n_pad, const double
     if (n == 0) return hipSuccess;
     if (result_in_rec && !P.rec) return hipErrorInvalidValue;
     if (result_in_rec) {
-        cov_rec_kernel<<<blocks_for(n, kChunk), kWG, 0, s>>>(P.rec, n, pc, m, idx_out, reject_d2, partial);
-        return hipGetLastError();
+        return launch(cov_rec_kernel, dim3(blocks_for(n, kChunk)), dim3(kWG), 0, s, P.rec, n, pc, m, idx_out, reject_d2, partial);
     }
-    cov_kernel<true><<<blocks_for(n, kChunk), kWG, 0, s>>>(P.x, P.y, P.z, n, n_pad, pc, Qz.x, Qz.y, Qz.z, Qz.rec, m, q_splits, keys,
+    return launch(cov_kernel<true>, dim3(blocks_for(n, kChunk)), dim3(kWG), 0, s, P.x, P.y, P.z, n, n_pad, pc, Qz.x, Qz.y, Qz.z, Qz.rec, m, q_splits, keys,
                                                            idxs, grid_rec, nullptr, idx_out, P.rec, reject_d2, partial);
-    return hipGetLastError();
 }
 
 hipError_t cov_from_idx(hipStream_t s, Soa3 P, size_t n, const double *pc, Soa3 Qz, size_t m, const uint32_t *idx,
                         double *partial)
 {
     if (n == 0) return hipSuccess;
-    cov_kernel<false><<<blocks_for(n, kChunk), kWG, 0, s>>>(P.x, P.y, P.z, n, 0, pc, Qz.x, Qz.y, Qz.z, Qz.rec, m, 1, nullptr, nullptr,
+    return launch(cov_kernel<false>, dim3(blocks_for(n, kChunk)), dim3(kWG), 0, s, P.x, P.y, P.z, n, 0, pc, Qz.x, Qz.y, Qz.z, Qz.rec, m, 1, nullptr, nullptr,
                                                             nullptr, idx, nullptr, nullptr, INFINITY, partial);
-    return hipGetLastError();
 }
 
 hipError_t solve(hipStream_t s, const double *partial, size_t count, const double *pc, const double *qc, double n_global,
                  double *out, double *extra)
 {
-    solve_kernel<<<1, kSolveWG, 0, s>>>(partial, count, pc, qc, n_global, out, extra);
-    return hipGetLastError();
+    return launch(solve_kernel, dim3(1), dim3(kSolveWG), 0, s, partial, count, pc, qc, n_global, out, extra);
 }
 
 hipError_t apply(hipStream_t s, Soa3 P, size_t n, const double *solve_rec, const uint32_t *idx, double *cen_partial)
 {
     if (n == 0) return hipSuccess;
     if (P.rec && !idx) return hipErrorInvalidValue;
-    apply_kernel<<<blocks_for(n, kChunk), kWG, 0, s>>>(P.x, P.y, P.z, n, solve_rec, idx, P.rec, cen_partial);
-    return hipGetLastError();
+    return launch(apply_kernel, dim3(blocks_for(n, kChunk)), dim3(kWG), 0, s, P.x, P.y, P.z, n, solve_rec, idx, P.rec, cen_partial);
 }
 
 size_t batch_lds_bytes(size_t m) { return (4 * ((m + 31) / 32 * 32) + 48 + 48) * sizeof(double); }   // the larger layout (records)
@@ -1255,9 +1240,8 @@ static hipError_t batch_launch(hipStream_t s, const double *P_in, const double *
         hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    kern<<<(unsigned)batch, kWG, lds, s>>>(P_in, Q_in, (unsigned)n, (unsigned)m, (unsigned)((m + 31) / 32 * 32), iters, P_out, rec_out,
+    return launch(kern, dim3((unsigned)batch), dim3(kWG), lds, s, P_in, Q_in, (unsigned)n, (unsigned)m, (unsigned)((m + 31) / 32 * 32), iters, P_out, rec_out,
                                            idx_out);
-    return hipGetLastError();
 }
 
 hipError_t batch_icp(hipStream_t s, int variant, const double *P_in, const double *Q_in, size_t batch, size_t n, size_t m,
@@ -1276,8 +1260,7 @@ hipError_t batch_icp(hipStream_t s, int variant, const double *P_in, const doubl
 hipError_t fourth_root(hipStream_t s, const double *d2, size_t n, double *key)
 {
     if (n == 0) return hipSuccess;
-    fourth_root_kernel<<<blocks_for(n, kWG), kWG, 0, s>>>(d2, n, key);
-    return hipGetLastError();
+    return launch(fourth_root_kernel, dim3(blocks_for(n, kWG)), dim3(kWG), 0, s, d2, n, key);
 }
 
 }  // namespace icpk

@@ -359,10 +359,8 @@ hipError_t mfma16_probe(hipStream_t s, Soa3 P, size_t n32, Soa3 Qz, size_t m32, 
                         unsigned long long *worst_bits)
 {
     if (n32 == 0 || m32 == 0 || n32 % 32 || m32 % 32 || !(qmax > 0.0)) return hipErrorInvalidValue;
-    mfma16_probe_kernel<<<dim3((unsigned)(n32 / 32), (unsigned)(m32 / 32)), 64, 0, s>>>(P.x, P.y, P.z, Qz.x, Qz.y, Qz.z, (const Half8 *)rec16,
-                                                                                      qmax, search_mfma16_scale(qmax), (unsigned)m_pad,
-                                                                                      worst_bits);
-    return hipGetLastError();
+    return launch(mfma16_probe_kernel, dim3((unsigned)(n32 / 32), (unsigned)(m32 / 32)), dim3(64), 0, s, P.x, P.y, P.z, Qz.x, Qz.y, Qz.z,
+                  (const Half8 *)rec16, qmax, search_mfma16_scale(qmax), (unsigned)m_pad, worst_bits);
 }
 
 // sigma: the power of two that puts qmax (the largest |q| of the centred target) into [2^6, 2^7)
@@ -376,9 +374,8 @@ double search_mfma16_scale(double qmax)
 hipError_t build_qrec16(hipStream_t s, Soa3 Qz, size_t m, size_t m_pad, double qmax, void *rec16)
 {
     if (m_pad == 0 || !(qmax > 0.0)) return hipErrorInvalidValue;
-    build_qrec16_kernel<<<(unsigned)((m_pad + kWG - 1) / kWG), kWG, 0, s>>>(Qz.x, Qz.y, Qz.z, m, m_pad, search_mfma16_scale(qmax),
-                                                                           (Half8 *)rec16);
-    return hipGetLastError();
+    return launch(build_qrec16_kernel, dim3((unsigned)((m_pad + kWG - 1) / kWG)), dim3(kWG), 0, s, Qz.x, Qz.y, Qz.z, m, m_pad,
+                  search_mfma16_scale(qmax), (Half8 *)rec16);
 }
 
 hipError_t search_mfma16(hipStream_t s, int groups, Soa3 P, size_t n_pad, const double *pc, Soa3 Qz, const void *rec16, double qmax,
@@ -394,14 +391,13 @@ hipError_t search_mfma16(hipStream_t s, int groups, Soa3 P, size_t n_pad, const 
     if (groups == G_) { \
         dim3 grid((unsigned)(n_pad / (128 * G_)), (unsigned)q_splits); \
         if (idx_prev) \
-            search_mfma16_kernel<G_, false><<<grid, kWG, 0, s>>>(P.x, P.y, P.z, pc, Qz.x, Qz.y, Qz.z, (const Half8 *)rec16, qmax, \
-                                                               sigma, (unsigned)n_pad, (unsigned)m, (unsigned)m_pad, m_scan, \
-                                                               q_per_split, idx_prev, out_key, out_idx); \
-        else   /* unseeded: many exact-path entries, handled by the wave cooperatively */ \
-            search_mfma16_kernel<G_, true><<<grid, kWG, 0, s>>>(P.x, P.y, P.z, pc, Qz.x, Qz.y, Qz.z, (const Half8 *)rec16, qmax, \
-                                                              sigma, (unsigned)n_pad, (unsigned)m, (unsigned)m_pad, m_scan, \
-                                                              q_per_split, idx_prev, out_key, out_idx); \
-        return hipGetLastError(); \
+            return launch(search_mfma16_kernel<G_, false>, grid, dim3(kWG), 0, s, P.x, P.y, P.z, pc, Qz.x, Qz.y, Qz.z, \
+                          (const Half8 *)rec16, qmax, sigma, (unsigned)n_pad, (unsigned)m, (unsigned)m_pad, m_scan, q_per_split, \
+                          idx_prev, out_key, out_idx); \
+        /* unseeded: many exact-path entries, handled by the wave cooperatively */ \
+        return launch(search_mfma16_kernel<G_, true>, grid, dim3(kWG), 0, s, P.x, P.y, P.z, pc, Qz.x, Qz.y, Qz.z, \
+                      (const Half8 *)rec16, qmax, sigma, (unsigned)n_pad, (unsigned)m, (unsigned)m_pad, m_scan, q_per_split, \
+                      idx_prev, out_key, out_idx); \
     }
     ICPK_CASE(2) ICPK_CASE(4)
 #undef ICPK_CASE

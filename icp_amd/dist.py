@@ -21,10 +21,12 @@ def shard_bounds(n_global, rank, world):
     return lo, min(n_global, lo + rpr)
 
 
-def exchange_partials(buf, width, rank, world, group=None):
+def exchange_partials(buf, width, rank, world, group=None, force=False):
     """All-gather of the rank-major partial array `buf` (world * chunks_per_rank * width doubles, torch tensor on
-    any device): every rank contributes its own slot and receives all others.  Works on "nccl" and "gloo"."""
-    if world == 1:
+    any device): every rank contributes its own slot and receives all others.  Works on "nccl" and "gloo".
+    world == 1 needs no exchange and issues none, unless `force` asks for the collective anyway (a one-rank process
+    group: the same RCCL call, enqueued on the same stream, as with eight ranks -- how the one-GPU box exercises it)."""
+    if world == 1 and not force:
         return buf
     import torch.distributed as td
     per = buf.numel() // world
@@ -43,14 +45,15 @@ def exchange_partials(buf, width, rank, world, group=None):
 class ShardedIcp:
     """Drives one engine per process.  world == 1 needs no torch at all."""
 
-    def __init__(self, P, Q, rank=0, world=1, device=0, search="auto", kernel_timing=False, group=None):
+    def __init__(self, P, Q, rank=0, world=1, device=0, search="auto", kernel_timing=False, group=None, force_collective=False):
         self.rank, self.world, self.group = rank, world, group
+        self.collective = world > 1 or force_collective   # exchange buffers + the two all-gathers per iteration
         n_global = len(P)
         lo, hi = shard_bounds(n_global, rank, world)
         self.lo, self.hi, self.n_local, self.n_global = lo, hi, hi - lo, n_global
         self.cov = self.cen = self.stream = None
         kw = dict(device=device, search=search, kernel_timing=kernel_timing)
-        if world > 1:
+        if self.collective:
             import torch
             cpr = chunks_per_rank(n_global, world)
             dev = torch.device("cuda", device)
@@ -77,19 +80,22 @@ class ShardedIcp:
     def begin(self):
         with self._on_stream():
             self.engine.step_begin()
-            exchange_partials(self.cen, CEN_W, self.rank, self.world, self.group)
+            if self.collective:
+                exchange_partials(self.cen, CEN_W, self.rank, self.world, self.group, force=True)
 
     def step(self):
         with self._on_stream():
             self.engine.step_search()
-            exchange_partials(self.cov, COV_W, self.rank, self.world, self.group)
+            if self.collective:
+                exchange_partials(self.cov, COV_W, self.rank, self.world, self.group, force=True)
             self.engine.step_update()
-            exchange_partials(self.cen, CEN_W, self.rank, self.world, self.group)
+            if self.collective:
+                exchange_partials(self.cen, CEN_W, self.rank, self.world, self.group, force=True)
 
     def gather_source(self):
         """The registered cloud, assembled on every rank (host arrays)."""
         local = self.engine.get_source()      # synchronises the engine's stream
-        if self.world == 1:
+        if not self.collective:
             return local
         import torch
         import torch.distributed as td

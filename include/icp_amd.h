@@ -208,6 +208,9 @@ int icp_amd_centroid(const double *A_xyz, size_t n, double out[3]);
  * sums live in a static device array of the library (384 KiB on every GPU the library runs on, held until the process
  * ends), which limits n to icp_amd_centroid_static_max_rows() = 16 Mi rows: larger n is ICP_AMD_EINVAL.  Every call on a
  * GPU shares that GPU's array, so calls that overlap on one GPU (different streams or host threads) race -- serialise them.
+ * Under stream capture: call icp_amd_init(device) BEFORE the capture begins.  The first call on a device otherwise looks up
+ * the scratch address (hipGetSymbolAddress) and loads the code objects, which need not be legal while a capture is open;
+ * after icp_amd_init the call only enqueues its two kernels on `stream` and is captured like any launch.
  * Result: bit-identical to icp_amd_centroid on the same rows. */
 int    icp_amd_centroid_static(const double *A_dev, size_t n, double *out_dev, int device, void *stream);
 size_t icp_amd_centroid_static_max_rows(void);

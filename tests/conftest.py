@@ -16,9 +16,12 @@ def pytest_configure(config):
 
 
 def golden(name):
+    """A committed fixture (tests/golden/*.npz, vectors from the unmodified reference).  A missing file is an ERROR, never a
+    skip: the fixtures are part of the tree, and a parity suite that quietly skips itself would still report success."""
     path = os.path.join(GOLDEN, name + ".npz")
     if not os.path.exists(path):
-        pytest.skip("golden fixture %s not present" % name)
+        pytest.fail("golden fixture %s is missing from tests/golden/ (it is committed with the tree: check .gpurunignore / "
+                    "the checkout)" % name, pytrace=False)
     with np.load(path, allow_pickle=False) as z:
         g = {k: z[k] for k in z.files}
     if "P" in g and "P_in_iters" in g and len(g["P_in_iters"]) and g["P_in_iters"][0] == 0:

@@ -103,7 +103,7 @@ def run_icp_case(name, P, Q, iters, keep_p=None, pfile=None, qfile=None, store_i
 CKPT = os.environ.get("GOLDEN_CKPT", "/tmp/golden_ckpt")
 
 
-def run_icp_case_resumable(name, P, Q, iters, keep_p, inputs_from):
+def run_icp_case_resumable(name, P, Q, iters, keep_p, inputs_from, store_p=False):
     """run_icp_case for the long runs (half an hour of reference time): one ref_trace process per iteration, each started
     from the cloud the previous one wrote (a %.17g CSV round trip is exact, and the reference re-centres the same Q every
     time, so the chain equals one long run bit for bit), with every iteration's outputs kept under $GOLDEN_CKPT so that an
@@ -139,6 +139,8 @@ def run_icp_case_resumable(name, P, Q, iters, keep_p, inputs_from):
     res = {k: np.stack(acc[k]) for k in keys}
     res.update(Qc=qc, P_out=cur, P_in=np.stack(p_in), P_in_iters=np.array([k for k in keep_p if k < iters], dtype=np.int32),
                inputs_from=np.array(inputs_from))
+    if store_p:   # the source cloud is this fixture's own; only the target comes from `inputs_from`
+        res["P"] = P
     np.savez_compressed(os.path.join(HERE, name + ".npz"), iters=np.int32(iters), **res)
     print("%-14s N=%d M=%d iters=%d  -> %s.npz" % (name, len(P), len(Q), iters, name))
 
@@ -252,6 +254,45 @@ def horse_tr1_x20():
 def bun045_000_x20():
     pf, qf = REF + "/icp/bun045.txt", REF + "/icp/bun000.txt"
     run_icp_case_resumable("bun045_000_x20", load_csv(pf), load_csv(qf), 20, [0, 1, 10, 19], "bun045_000")
+
+
+# The rest of data/icp (BASELINE configs[1] is "data/icp sample clouds"): the second horse pose for the full 20 iterations,
+# and the three remaining bunny scans against bun000 (N != M: 40251 / 31701 / 35336 source rows against 40256 targets) for one
+# iteration of the reference loop each.  Targets are those of horse_tr1 / bun045_000 and are not stored again.
+@case
+def horse_tr2_x20():
+    pf, qf = REF + "/icp/horse_tr2.txt", REF + "/icp/horse_ref.txt"
+    run_icp_case_resumable("horse_tr2_x20", load_csv(pf), load_csv(qf), 20, [0, 10], "horse_tr1", store_p=True)
+
+
+def bun_case(scan):
+    pf, qf = REF + "/icp/%s.txt" % scan, REF + "/icp/bun000.txt"
+    P, Q = load_csv(pf), load_csv(qf)
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "trace.bin")
+        subprocess.check_call([TRACE, pf, qf, "1", out, "1"])
+        tr = read_trace(out)
+    assert np.array_equal(tr["P_in"][0], P), scan
+    name = scan + "_000"
+    keep = {k: tr[k] for k in ("Qc", "Pc", "idx", "cov", "S", "R", "t")}
+    # P_out is left out (1 MB of incompressible doubles per scan): the transform apply is pinned bit for bit elsewhere
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), P=P, inputs_from=np.array("bun045_000"), iters=np.int32(1), **keep)
+    print("%-14s N=%d M=%d iters=1 -> %s.npz" % (name, len(P), len(Q), name))
+
+
+@case
+def bun180_000():
+    bun_case("bun180")
+
+
+@case
+def bun270_000():
+    bun_case("bun270")
+
+
+@case
+def bun315_000():
+    bun_case("bun315")
 
 
 @case

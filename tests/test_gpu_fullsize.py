@@ -22,11 +22,11 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-9
 
 
-@pytest.mark.parametrize("name", ["horse_tr1_x20", "bun045_000_x20"])
+@pytest.mark.parametrize("name", ["horse_tr1_x20", "bun045_000_x20", "horse_tr2_x20"])
 def test_config2_sample_clouds_20_iterations(name):
     g = golden(name)
     base = golden(str(g["inputs_from"]))
-    P, Q, iters = base["P"], base["Q"], int(g["iters"])
+    P, Q, iters = (g["P"] if "P" in g else base["P"]), base["Q"], int(g["iters"])   # horse_tr2: its own source, horse_tr1's target
     assert iters == 20
     P_out, tr = icp_amd.icp_gpu_optimized(P, Q, iters, "-shared-loop", trace=True)
     mism = int((tr["idx"] != g["idx"]).sum())
@@ -52,6 +52,34 @@ def test_config2_sample_clouds_20_iterations(name):
             assert np.array_equal(idx, g["idx"][it]), (name, it, search)
             seeded = icp_amd.correspondences_seeded(P_in, g["Pc"][it], Qz, g["idx"][it - 1], search=search, q_splits=3)
             assert np.array_equal(seeded, g["idx"][it]), (name, it, search, "seeded")
+
+
+@pytest.mark.parametrize("name", ["bun180_000", "bun270_000", "bun315_000"])
+def test_config2_remaining_bunny_scans_one_iteration(name):
+    """The rest of data/icp: bun180 / bun270 / bun315 against bun000 (N != M: 40 251 / 31 701 / 35 336 source rows, 40 256
+    targets), one iteration of the reference loop each -- every search variant at stage level, then the engine (AUTO = grid,
+    and the brute-force search of the benchmark) for that iteration."""
+    g = golden(name)
+    P, Q, Qc = g["P"], golden(str(g["inputs_from"]))["Q"], g["Qc"]
+    assert len(P) != len(Q)
+    want = g["idx"][0]
+    Qz = orc.sub_row(Q, Qc)
+    assert relerr(icp_amd.centroid(Q), Qc) < 1e-13 and relerr(icp_amd.centroid(P), g["Pc"][0]) < 1e-13
+    for search, splits in (("f32", 1), ("f32", 7), ("grid", 1), ("fma", 3), ("exact", 2)):
+        idx = icp_amd.correspondences(P, g["Pc"][0], Qz, search=search, q_splits=splits)
+        assert np.array_equal(idx, want), (name, search, splits, int((idx != want).sum()))
+    assert relerr(icp_amd.cross_cov(P, g["Pc"][0], Qz, want), g["cov"][0]) < 1e-12
+    for search in ("auto", "f32"):
+        e = icp_amd.Engine(search=search)
+        e.set_target(Q)
+        e.set_source(P)
+        e.iterate(1)
+        last = e.get_last()
+        e.close()
+        assert np.array_equal(last["idx"], want), (name, search)
+        assert relerr(last["Pc"], g["Pc"][0]) < TOL and relerr(last["cov"], g["cov"][0]) < TOL
+        assert relerr(last["R"], g["R"][0]) < TOL and relerr(last["S"], g["S"][0]) < TOL
+        assert relerr_t(last["t"], g["t"][0], Qc, g["Pc"][0]) < TOL
 
 
 def _rows_fixture(name):

@@ -399,6 +399,81 @@ def test_cli_matches_reference_output(tmp_path):
     assert r.returncode != 0 and "Invalid method, must be: -shared|-loop|-shared-loop|-batch" in r.stderr
 
 
+def test_cli_five_column_cloud_aborts_like_the_reference(tmp_path):
+    """data/icp/cow_tr2.txt has FIVE columns (Points_0..2, Points_Magnitude, Point ID).  The reference reads it and aborts
+    with an uncaught runtime_error -- `element_wise_reduce requires arrays to be broadcastable` (src/libalg/alg.cpp:21;
+    observed on oracle/_ref/CPUICP cow_tr2 cow_ref 5: that text on stderr, SIGABRT) -- and GPUICP does the same: same text,
+    abort status, no result file, nothing on stdout."""
+    exe = os.path.join(ROOT, "bin", "GPUICP")
+    g = golden("cow_tr1")
+    P, Q = g["P"], g["Q"]
+    with open(tmp_path / "cow_tr2.txt", "w") as f:
+        f.write("Points_0,Points_1,Points_2,Points_Magnitude,Point ID\n")
+        for k, r in enumerate(P):
+            f.write("%.6g,%.6g,%.6g,%.6g,%d\n" % (r[0], r[1], r[2], float(np.sqrt((r * r).sum())), k))
+    with open(tmp_path / "cow_ref.txt", "w") as f:
+        f.write("Points_0,Points_1,Points_2\n")
+        for r in Q:
+            f.write("%.17g,%.17g,%.17g\n" % tuple(r))
+    A, hdr = icp_amd.read_csv(tmp_path / "cow_tr2.txt")
+    assert A.shape == (len(P), 5) and hdr.startswith("Points_0,Points_1,Points_2,Points_Magnitude,Point ID")
+    for method in ("-shared-loop", "-batch"):
+        r = subprocess.run([exe, "cow_tr2.txt", "cow_ref.txt", "5", method], cwd=tmp_path, capture_output=True, text=True, timeout=120)
+        assert r.returncode in (-6, 134), (r.returncode, r.stderr)
+        assert "element_wise_reduce requires arrays to be broadcastable" in r.stderr and r.stdout == ""
+        assert not os.path.exists(tmp_path / "point_cloud_result")
+    # the other way round (5-column target) ends the same way
+    r = subprocess.run([exe, "cow_ref.txt", "cow_tr2.txt", "5", "-loop"], cwd=tmp_path, capture_output=True, text=True, timeout=120)
+    assert r.returncode in (-6, 134) and "element_wise_reduce requires arrays to be broadcastable" in r.stderr
+
+
+def test_device_svd_against_numpy_on_random_and_degenerate_covariances():
+    """icp_amd_solve (the one-sided Jacobi of kernels.hip) against numpy.linalg.svd -- LAPACK gesdd, an algorithm that shares
+    nothing with the device's or the oracle's Jacobi -- on covariances no fixture holds: random, ill-conditioned,
+    negative-determinant (R = U V^T is then a reflection: the reference has no det fix, src/cpu/icp.cpp:218-221), rank 2 and
+    rank 1.  S within 1e-9 of S0; R = U V^T within 1e-9 wherever it is unique (S2 > 1e-6 S0); for rank-2 input R is unique up
+    to the sign of u3 v3^T; R is orthogonal in every case and t = Qc - Pc R^T."""
+    rng = np.random.RandomState(77)
+    cases = []
+    for k in range(220):
+        U, _ = np.linalg.qr(rng.standard_normal((3, 3)))
+        V, _ = np.linalg.qr(rng.standard_normal((3, 3)))
+        kind = k % 5
+        if kind == 0:
+            A = rng.standard_normal((3, 3)) * 10.0 ** rng.uniform(-6, 6)
+        elif kind == 1:   # ill-conditioned but nonsingular
+            A = U @ np.diag([1.0, 10.0 ** rng.uniform(-5, 0), 10.0 ** rng.uniform(-5.5, -5)]) @ V.T * 10.0 ** rng.uniform(-3, 3)
+        elif kind == 2:   # negative determinant
+            A = rng.standard_normal((3, 3))
+            if np.linalg.det(A) > 0:
+                A[0] = -A[0]
+            A *= 10.0 ** rng.uniform(-2, 4)
+        elif kind == 3:   # rank 2 (a planar cloud in general position)
+            A = U @ np.diag([rng.uniform(1, 5), rng.uniform(0.1, 1), 0.0]) @ V.T
+        else:             # rank 1
+            A = np.outer(U[:, 0], V[:, 0]) * rng.uniform(0.5, 50)
+        cases.append((kind, A))
+    worst = 0.0
+    for kind, A in cases:
+        Pc, Qc = rng.uniform(-3, 3, 3), rng.uniform(-3, 3, 3)
+        R, t, S = icp_amd.solve(A, Pc, Qc)
+        Un, Sn, Vtn = np.linalg.svd(A)
+        assert np.abs(S - Sn).max() <= 1e-9 * Sn[0], (kind, S, Sn)
+        assert np.abs(R.T @ R - np.eye(3)).max() < 1e-12, kind                     # orthogonal, reflection or not
+        assert np.abs(t - (Qc - R @ Pc)).max() < 1e-12 * max(1.0, np.abs(Pc).max(), np.abs(Qc).max())
+        Rn = Un @ Vtn
+        if Sn[2] > 1e-6 * Sn[0]:
+            err = np.abs(R - Rn).max()
+            assert err < TOL, (kind, err, Sn)
+            assert np.sign(np.linalg.det(R)) == np.sign(np.linalg.det(A))           # no reflection fix
+            worst = max(worst, err)
+        elif Sn[1] > 1e-6 * Sn[0]:
+            # rank 2: u3, v3 are determined up to one sign each, so U V^T is one of two matrices
+            flip = Rn - 2.0 * np.outer(Un[:, 2], Vtn[2])
+            assert min(np.abs(R - Rn).max(), np.abs(R - flip).max()) < 1e-8, (kind, Sn)
+    assert worst < TOL
+
+
 @pytest.mark.skipif(not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "CPUICP")), reason="needs the built oracle/_ref/CPUICP")
 def test_cli_against_the_reference_executable_on_random_pairs(tmp_path):
     """The two executables side by side on inputs no fixture holds: oracle/_ref/CPUICP (the reference's src/cpu/main.cpp,

@@ -126,7 +126,8 @@ def test_bench_two_ranks_on_one_gpu_over_gloo():
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["parallelism"] == "p-shard2"
-    assert d["process_group"] == {"ranks": 2, "backend": "gloo"} and d["rccl_ranks"] == 0   # gloo rehearsal: no RCCL rank
+    assert d["process_group"] == {"ranks": 2, "backend": "gloo", "forced_single_rank": False}
+    assert d["rccl_ranks"] == 0                                       # gloo rehearsal: no RCCL call was issued
     assert len(d["search_ms_per_rank"]["values"]) == 2 and d["search_ms_per_rank"]["min"] > 0
     assert set(d["collective_ms"]) == {"cov_partials", "centroid_partials"}
     assert d["rt_crosscheck"]["ranks_identical_to_rank0"] == 2      # every rank solved the same R, t, bit for bit
@@ -139,6 +140,57 @@ def test_bench_two_ranks_on_one_gpu_over_gloo():
     assert r1.returncode == 0, r1.stderr[-3000:]
     d1 = json.loads([ln for ln in r1.stdout.splitlines() if ln.startswith("{")][-1])
     assert d1["rms_last"] == d["rms_last"]
+
+
+def test_bench_real_rccl_exchange_with_a_one_rank_process_group():
+    """The exchange the multi-GPU benchmark relies on, executed for real on the one GPU of this box: ICP_AMD_BENCH_FORCE_PG=1
+    makes bench.py create an RCCL process group of ONE rank (torch backend "nccl", device_id bound) and send the two
+    all-gathers of every iteration through it -- td.all_gather_into_tensor on the engine's stream, the CUDA-tensor
+    all_reduce / broadcast of the bench's own bookkeeping -- exactly the calls eight ranks issue.  Same registration as the
+    plain run (no process group, no collective): identical rms, bit for bit."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--src", "60000", "--tgt", "50000",
+            "--no-cpu-baseline", "--no-fp64-variants", "--no-batch"]
+    env = dict(os.environ, OMP_NUM_THREADS="4")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "ICP_AMD_BENCH_BACKEND", "ICP_AMD_BENCH_DEVICE"):
+        env.pop(k, None)
+    out = {}
+    for name, extra in (("forced", {"ICP_AMD_BENCH_FORCE_PG": "1"}), ("plain", {})):
+        r = subprocess.run(base, env=dict(env, **extra), capture_output=True, text=True, timeout=280)
+        assert r.returncode == 0, (name, r.stdout[-2000:] + r.stderr[-4000:])
+        out[name] = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    d, d1 = out["forced"], out["plain"]
+    assert d["process_group"] == {"ranks": 1, "backend": "rccl (torch 'nccl')", "forced_single_rank": True}
+    assert d["rccl_ranks"] == 1 and d["n_gpus"] == 1
+    assert set(d["collective_ms"]) == {"cov_partials", "centroid_partials"}
+    assert all(v["ms"] > 0 and v["bytes"] > 0 for v in d["collective_ms"].values())
+    assert d["rt_crosscheck"] == dict(d["rt_crosscheck"], ranks_identical_to_rank0=1, of=1)
+    assert d1["process_group"]["backend"] == "none" and d1["rccl_ranks"] == 0 and "collective_ms" not in d1
+    assert d["rms_last"] == d1["rms_last"] and d["rms_last"] > 0
+    assert d["grid_search"]["iters_per_sec"] > 0 and d["config"]["search"]["variant"] == "f32"
+
+
+def test_bench_child_launch_has_a_time_limit_of_its_own():
+    """`python bench.py --gpus 2` starts its ranks as a child process; a child that does not finish within
+    ICP_AMD_BENCH_LAUNCH_TIMEOUT seconds is killed (its whole process group), what it had printed is reported and the exit
+    status is non-zero -- a hung RCCL initialisation no longer runs silently into the caller's own limit."""
+    import os
+    import subprocess
+    import sys
+    import time
+    from conftest import ROOT
+    env = dict(os.environ, ICP_AMD_BENCH_DEVICE="0", ICP_AMD_BENCH_BACKEND="gloo", ICP_AMD_BENCH_LAUNCH_TIMEOUT="1", OMP_NUM_THREADS="4")
+    env.pop("WORLD_SIZE", None)
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"], env=env,
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 124, (r.returncode, r.stderr[-2000:])
+    assert "did not finish within 1 s and was killed" in r.stderr
+    assert time.time() - t0 < 60
 
 
 def test_native_multi_cross_check_of_the_redundant_solves(monkeypatch):

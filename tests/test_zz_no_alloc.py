@@ -40,6 +40,47 @@ def test_static_centroid_equals_allocating_entry_point_two_calls_in_a_row():
         assert np.array_equal(_static_centroid(rows, st), icp_amd.centroid(rows)), len(rows)
 
 
+def test_static_centroid_allocates_nothing_and_runs_under_stream_capture(monkeypatch):
+    """The property the entry point exists for.  (a) Free device memory (hipMemGetInfo) and the bytes the library's own block
+    cache holds are the same before and after a call, with the cache switched off (ICP_AMD_CACHE_MB=0) so that nothing could
+    hide an allocation.  (b) The call is legal inside hipStreamBeginCapture ... EndCapture -- where hipMalloc is not -- after
+    icp_amd_init(device) (which takes the scratch address with hipGetSymbolAddress up front, as the header asks of capture
+    users): captured into a graph, replayed on new input in the same buffers, same bits as icp_amd_centroid each time."""
+    monkeypatch.setenv("ICP_AMD_CACHE_MB", "0")
+    dev = torch.device("cuda", 0)
+    icp_amd.init(0)
+    icp_amd.cache_trim()
+    P, _ = synth.make_pair(200000, 1000, seed=92)
+    a = torch.from_numpy(np.ascontiguousarray(P)).to(dev)
+    out = torch.zeros(3, dtype=torch.float64, device=dev)
+    st = torch.cuda.Stream(dev)
+    icp_amd.centroid_static(a.data_ptr(), len(P), out.data_ptr(), device=0, stream=st.cuda_stream)   # code objects loaded
+    st.synchronize()
+    torch.cuda.synchronize()
+    free0, held0 = torch.cuda.mem_get_info(dev)[0], icp_amd.cache_trim()
+    for rows in (len(P), 4097, len(P)):
+        icp_amd.centroid_static(a.data_ptr(), rows, out.data_ptr(), device=0, stream=st.cuda_stream)
+    st.synchronize()
+    free1, held1 = torch.cuda.mem_get_info(dev)[0], icp_amd.cache_trim()
+    assert free1 == free0 and held0 == held1 == 0, (free0, free1, held0, held1)
+    assert np.array_equal(out.cpu().numpy(), icp_amd.centroid(P))
+    # (b) under stream capture
+    out.zero_()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=st):
+        icp_amd.centroid_static(a.data_ptr(), len(P), out.data_ptr(), device=0, stream=torch.cuda.current_stream(dev).cuda_stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), np.zeros(3))        # captured, not run
+    graph.replay()
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), icp_amd.centroid(P))
+    P2 = P[::-1] * 2.5 - 1.0
+    a.copy_(torch.from_numpy(np.ascontiguousarray(P2)))
+    graph.replay()
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), icp_amd.centroid(P2))
+
+
 def test_static_centroid_rejects_what_its_scratch_cannot_hold():
     limit = icp_amd.centroid_static_max_rows()
     assert limit == 16 << 20
