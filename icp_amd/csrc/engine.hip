@@ -974,6 +974,11 @@ struct MultiRun {
     std::vector<Rccl::comm_t> comm;
     bool by_copies = false;                 // exchange with peer copies instead of RCCL (a device listed twice; ICP_AMD_MULTI_EXCHANGE=copy)
     std::vector<hipEvent_t> ready, done;    // by_copies: per engine, "my slot is written" / "I have read everybody's slot"
+    // RCCL's set-up and tear-down probe devices and peers and leave a stale 'invalid device ordinal' in the host thread's
+    // sticky error word even when they succeed; the next HIP user of the process (torch, the host application) would report
+    // it as its own failure.  The word was clean when this run began (`clean`): whatever is in it afterwards is the probing's.
+    const bool clean = hipPeekAtLastError() == hipSuccess;
+    void drop_probe_error() const { if (clean) (void)hipGetLastError(); }
     ~MultiRun()
     {
         for (icp_amd_engine *e : eng) icp_amd_destroy(e);
@@ -986,6 +991,7 @@ struct MultiRun {
         }
         for (Rccl::comm_t c : comm)
             if (c) g_rccl.CommDestroy(c);
+        drop_probe_error();
     }
 };
 
@@ -1091,12 +1097,13 @@ extern "C" int icp_amd_run_multi(const double *P, size_t n, const double *Q, siz
                 if (r.dev[h] == r.dev[g]) continue;
                 int can = 0;
                 HIPCHK(hipDeviceCanAccessPeer(&can, r.dev[g], r.dev[h]));
-                if (can && hipDeviceEnablePeerAccess(r.dev[h], 0) == hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
+                if (can && hipDeviceEnablePeerAccess(r.dev[h], 0) == hipErrorPeerAccessAlreadyEnabled) r.drop_probe_error();
             }
         }
     } else {
         const int rc = g_rccl.CommInitAll(r.comm.data(), G, r.dev.data());
         if (rc != 0) return fail(ICP_AMD_EHIP, "ncclCommInitAll failed: %s", g_rccl.GetErrorString(rc));
+        r.drop_probe_error();
     }
     std::vector<size_t> lo(G), cnt(G);
     for (int g = 0; g < G; ++g) {

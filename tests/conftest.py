@@ -15,6 +15,25 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(autouse=True)
+def no_sticky_hip_error_left_behind(request):
+    """After every GPU test: the host thread's sticky HIP error word (hipPeekAtLastError) is clean.  The library reports its
+    launches through their own return codes and clears nothing on behalf of others, so anything it left there would
+    surface later as somebody else's failure (round 2: torch raised 'invalid device ordinal' for RCCL's leftover)."""
+    yield
+    if request.node.get_closest_marker("gpu") is None:
+        return
+    import ctypes
+    try:
+        hip = ctypes.CDLL("libamdhip64.so")
+    except OSError:
+        return
+    err = int(hip.hipPeekAtLastError())
+    if err != 0:
+        hip.hipGetLastError()          # do not let one leak fail every later test as well
+        pytest.fail("%s left sticky HIP error %d behind" % (request.node.nodeid, err), pytrace=False)
+
+
 def golden(name):
     """A committed fixture (tests/golden/*.npz, vectors from the unmodified reference).  A missing file is an ERROR, never a
     skip: the fixtures are part of the tree, and a parity suite that quietly skips itself would still report success."""

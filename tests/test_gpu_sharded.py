@@ -12,6 +12,13 @@ pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 
 
+def sticky_hip_error():
+    """hipPeekAtLastError() of this host thread: the process-wide sticky error word the library must neither leave dirty
+    (torch would report the leftover as its own failure) nor clear on behalf of others."""
+    import ctypes
+    return int(ctypes.CDLL("libamdhip64.so").hipPeekAtLastError())
+
+
 def run_sharded(P, Q, world, iters):
     n = len(P)
     cpr = icp_amd.chunks_per_rank(n, world)
@@ -200,8 +207,12 @@ def test_native_multi_cross_check_of_the_redundant_solves(monkeypatch):
     monkeypatch.setenv("ICP_AMD_MULTI_CROSSCHECK", "1")
     P, Q = synth.make_pair(9000, 8000, seed=47)
     want = icp_amd.icp_gpu_optimized(P, Q, 4)
+    assert sticky_hip_error() == 0
     assert np.array_equal(icp_amd.icp_gpu_multi(P, Q, 4, 1, devices=[0]), want)            # RCCL, one rank
+    assert sticky_hip_error() == 0            # RCCL's device probing leaves no stale error behind our entry point
     assert np.array_equal(icp_amd.icp_gpu_multi(P, Q, 4, 3, devices=[0, 0, 0]), want)      # peer-copy exchange, three shards
+    assert sticky_hip_error() == 0
+    torch.zeros(4, device="cuda").sum().item()   # ... so the next HIP user of the process (torch) is not handed one
 
 
 def test_native_rccl_multi_entry_point():

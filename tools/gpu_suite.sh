@@ -1,11 +1,14 @@
 #!/bin/bash
 # GPU suite + default bench on the tree's library; each step under its own limit, nothing runs after a failed step
+# usage: tools/gpu_suite.sh <tag> [extra pytest arguments, e.g. --deselect ...]
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-/root/repo}
-O=$R/gpurun_out/${1:-suite}
+TAG=${1:-suite}
+shift
+O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd $R
-timeout -k 10 700 python -u -m pytest tests -m gpu -x -q --timeout 300 --timeout-method thread --durations=8 > $O/pytest.txt 2>&1
+timeout -k 10 900 python -u -m pytest tests -m gpu -x -v --timeout 300 --timeout-method thread --durations=12 "$@" > $O/pytest.txt 2>&1
 rc=$?
 tail -25 $O/pytest.txt
 [ $rc -ne 0 ] && exit $rc
@@ -15,5 +18,6 @@ timeout -k 10 400 python bench.py > $O/bench.json 2> $O/bench.err || { tail -5 $
 python - <<PY
 import json
 d=json.load(open("$O/bench.json"))
-print({k:d[k] for k in ("value","ms_per_step","first_step_ms")}, d["roofline"]["avg_launch_ms"], d["grid_search"]["ms_per_step"])
+print({k:d[k] for k in ("value","ms_per_step","first_step_ms")}, d["roofline"]["avg_launch_ms"], d["grid_search"]["ms_per_step"],
+      d["grid_search"]["first_steps"]["ms_per_step"], d.get("batch_mode", {}).get("registrations_per_sec"))
 PY
