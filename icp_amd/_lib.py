@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libicp_amd.so")
+LIB_PATH = os.environ.get("ICP_AMD_LIB") or os.path.join(_HERE, "libicp_amd.so")   # ICP_AMD_LIB: another build of the same ABI (A/B runs)
 
 OK, EINVAL, ENODEV, EHIP, ENOMEM, EIO, ESTATE = 0, -1, -2, -3, -4, -5, -6
 METHODS = {"-shared-loop": 0, "-shared": 1, "-loop": 2, "-batch": 3}

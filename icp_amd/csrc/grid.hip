@@ -340,32 +340,10 @@ __global__ __launch_bounds__(kWG) void grid_occupied_kernel(const uint32_t *__re
     if ((threadIdx.x & 63) == 0 && mine) atomicAdd(out, mine);
 }
 
-// One lane per source point for everything but the walk over the cells.  The walk is done by the WAVE: the candidates of
-// its (up to 64) walking rows -- every row needs a different number, 16 on average, and a lane walking its own box alone
-// keeps its wave busy for the longest walk while its loads hit a different cache line in every lane -- are laid out as one
-// sequence of (row, candidate) pairs and dealt to the lanes 64 at a time, so consecutive lanes read consecutive target
-// records and every lane-slot does work; the smallest and second smallest d^2 of each row are combined in LDS.
-// A row whose box is large (more than row_cap rows of cells or eval_cap targets -- an outlier far from every target, or an
-// un-seeded first pass) is not walked here while the rest of its wave waits: it records what it has found so far and
-// queues the point for search_grid_overflow_kernel.
-constexpr int kWalkRows = 4;   // rows of cells a walking row contributes to one round of its wave
-// per-wave LDS of the cooperative walk: the walking rows' positions, their runs of target records in this round, and the
-// (smallest d^2, where, second smallest d^2) of each row's current pass
-template <int UN>
-struct WalkLds {
-    double ax[64], ay[64], az[64];
-    unsigned long long d1[64], d2[64];   // bit patterns of non-negative doubles: they order like the values
-    uint32_t run[64][2 * kWalkRows];     // o[0..3]: flattened position -> sorted position, per run; ce[0..2]: where runs end; total
-    uint32_t pre[64];                    // first pair of each row in the round's sequence
-    uint32_t k1[64];
-    uint32_t own[64 * UN];               // (tag, row slot) at the pair where a row's candidates begin
-};
-__device__ __forceinline__ void wave_sync()   // the wave's own LDS traffic is in program order; this only pins the compiler to it
-{
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-}
-template <int UN>   // pairs per lane in flight (record loads issued together)
+// One lane per source point.  A lane whose box is large (more than row_cap rows of cells or eval_cap targets -- an
+// outlier far from every target, or an un-seeded first pass) does not walk it alone while the other 63 lanes of its
+// wave wait: it records what it has found so far and queues the point for search_grid_overflow_kernel.
+template <int ROWS, int FLIGHT>   // rows of cells per group (their runs are walked as one sequence); record loads in flight per lane
 __global__ __launch_bounds__(kWG) void search_grid_kernel(const double *__restrict__ px, const double *__restrict__ py,
                                                           const double *__restrict__ pz, double *__restrict__ pc_io, size_t n,
                                                           GridDesc g, const uint32_t *__restrict__ start,
@@ -505,11 +483,10 @@ __global__ __launch_bounds__(kWG) void search_grid_kernel(const double *__restri
         }
         return true;
     };
-    // Rows that walk are rare once certificates hold, but nearly every wave has a few: the workgroup gathers its walking
-    // rows and packs them into as few waves as they need; the other waves leave.
+    // Rows that walk are rare once certificates hold, but nearly every wave has a few, and a wave is as slow as its slowest
+    // lane: the workgroup gathers its walking rows and packs them into as few waves as they need; the other waves leave.
     __shared__ uint32_t s_walk[kWG];
     __shared__ uint32_t s_walkers;
-    __shared__ WalkLds<UN> s_wl[kWG / 64];
     if (threadIdx.x == 0) s_walkers = 0;
     __syncthreads();
     bool need = l < n && setup();
@@ -519,171 +496,102 @@ __global__ __launch_bounds__(kWG) void search_grid_kernel(const double *__restri
     if (stat && threadIdx.x == 0) atomicAdd(&stat[0], (unsigned long long)walkers);
     const size_t left = n - (size_t)blockIdx.x * kWG;
     if (walkers + 64 <= (left < (size_t)kWG ? left : (size_t)kWG)) {   // packing frees at least one wave
-        if ((threadIdx.x & ~63u) >= walkers) return;   // whole waves only: the lanes of a wave that walks stay with it
-        need = threadIdx.x < walkers;
-        if (need) {
-            i = s_walk[threadIdx.x];
-            need = setup();   // the same decision again (walking rows have written nothing), now with this row's state
-        }
-    }
-    if (!__ballot(need)) return;   // (no __syncthreads below: the waves of the workgroup are on their own from here)
-    // ---- the walk, by the wave --------------------------------------------------------------------------------------
-    // Per row (lane): radius r -> box -> passes.  A pass meets every target of the box's cells exactly once (the seed
-    // included) and ends with d1 / d2 = the smallest and the second smallest d^2 met and k1 = where the smallest sits: keys
-    // (two square roots each) are not needed to find the winner of a pass -- with d2 outside the tie band of d1 that target
-    // has the strictly smallest key; only otherwise (near-ties, duplicated targets, lattices) the box is walked once more
-    // below, comparing (key, index) among the targets inside the band, which are the only ones that can hold the smallest key.
-    // The cells cx0..cx1 of one (cy, cz) row of cells are adjacent in the sorted arrays: a row of cells is one run [k0, k1)
-    // of target records.  Each round, every walking row puts its next kWalkRows runs on the table; the wave flattens all of
-    // them into one sequence of pairs (row, target) and takes it 64 * UN pairs at a time.
-    WalkLds<UN> &W = s_wl[threadIdx.x >> 6];
-    const unsigned lane = threadIdx.x & 63;
-    constexpr unsigned long long kInfBits = 0x7FF0000000000000ull;
-    bool active = need, fresh = need, defer = false;
-    double r = need ? first_radius(g, ax, ay, az, amax, edge) : 0.0;
-    unsigned evals = 0;
-    double Bfinal = 0.0;
-    Box b{};
-    int cy = 0, cz = 0;
-    uint32_t tag = 0, carry = 0;
-    W.ax[lane] = ax; W.ay[lane] = ay; W.az[lane] = az;
-#pragma unroll
-    for (int j = 0; j < UN; ++j) W.own[64 * j + lane] = 0;   // tags start at 1: nothing left in LDS passes for a mark
-    for (;;) {
-        // (1) rows that begin a pass lay out their box
-        long rows = 0;
-        if (active && fresh) {
-            b = make_box(g, ax, ay, az, r);
-            Bfinal = b.all ? INFINITY : b.B;
-            cy = b.cy0;
-            cz = b.cz0;
-            W.d1[lane] = kInfBits;
-            W.d2[lane] = kInfBits;
-            rows = (long)(b.cy1 - b.cy0 + 1) * (long)(b.cz1 - b.cz0 + 1);
-        }
-        if (ovf_list) {
-            // A large box is handed over when it would keep the wave busy for one row (an outlier); when most rows of the
-            // wave have large boxes (an un-seeded pass over a scan, whose cells are mostly empty) they are all walked here,
-            // up to 16 times the caps.
-            const bool big = active && fresh && rows > (long)row_cap;
-            const int n_big = __popcll(__ballot(big)), n_act = __popcll(__ballot(active));
-            if (big && (defer_always || rows > 16L * row_cap || 4 * n_big < n_act)) {
-                defer = true;
-                active = false;
-            }
-        }
-        fresh = false;
-        // (2) the next kWalkRows rows of cells of every walking row: their cell-start loads go out together
-        uint32_t o[kWalkRows], ce[kWalkRows], total = 0;
-#pragma unroll
-        for (int u = 0; u < kWalkRows; ++u) {
-            uint32_t a0 = 0, a1 = 0;
-            if (active && cz <= b.cz1) {
-                const size_t row = ((size_t)cz * (size_t)g.dim[1] + (size_t)cy) * (size_t)g.dim[0];
-                a0 = start[row + b.cx0];
-                a1 = start[row + b.cx1 + 1];
-                if (++cy > b.cy1) { cy = b.cy0; ++cz; }
-            }
-            o[u] = a0 - total;   // position t of the flattened runs -> sorted position t + o[u] for t in [ce[u-1], ce[u])
-            total += a1 - a0;
-            ce[u] = total;
-        }
-        evals += total;
-        if (ovf_list) {
-            const bool over = active && evals > eval_cap;
-            const int n_over = __popcll(__ballot(over));   // rows of the wave that are past the cap here
-            if (over && (defer_always || evals > 16u * eval_cap || 4 * n_over < 64)) {
-                defer = true;
-                active = false;
-                total = 0;
-            }
-        }
-        if (!__ballot(active)) break;
-        // (3) the round's sequence: row `lane` owns the pairs [pre, pre + total)
-        uint32_t incl = total;
-#pragma unroll
-        for (int sh = 1; sh < 64; sh <<= 1) {
-            const uint32_t up = __shfl_up(incl, sh, 64);
-            if (lane >= (unsigned)sh) incl += up;
-        }
-        const uint32_t pre = incl - total;
-        const uint32_t T = __shfl(incl, 63, 64);
-        W.pre[lane] = pre;
-#pragma unroll
-        for (int u = 0; u < kWalkRows; ++u) W.run[lane][u] = o[u];
-#pragma unroll
-        for (int u = 0; u < kWalkRows; ++u) W.run[lane][kWalkRows + u] = ce[u];
-        wave_sync();
-        // (4) 64 * UN pairs per step.  Which row a pair belongs to: every row marks the pair its candidates begin with; a
-        // pair's row is that of the last mark at or before it (a ballot and a count of leading zeros), or the row the
-        // previous block ended with.
-        for (uint32_t base = 0; base < T; base += 64u * UN) {
-            if (++tag == (1u << 26)) {   // the tag field is full (never in practice): start over with clean marks
-                tag = 1;
-#pragma unroll
-                for (int j = 0; j < UN; ++j) W.own[64 * j + lane] = 0;
-                wave_sync();
-            }
-            if (total > 0 && pre >= base && pre - base < 64u * UN) W.own[pre - base] = (tag << 6) | lane;
-            wave_sync();
-            double4 v[UN];
-            uint32_t wrow[UN], kk[UN];
-            bool valid[UN];
-#pragma unroll
-            for (int j = 0; j < UN; ++j) {
-                const uint32_t p = base + 64u * j + lane;
-                const uint32_t mark = W.own[64 * j + lane];
-                const bool head = (mark >> 6) == tag;
-                const unsigned long long hb = __ballot(head) & (~0ull >> (63 - lane));   // marks at or before this lane
-                const uint32_t from = __shfl(mark, hb ? 63 - __clzll(hb) : 0, 64) & 63u;
-                const uint32_t w = hb ? from : carry;
-                carry = __shfl(w, 63, 64);
-                valid[j] = p < T;
-                wrow[j] = w;
-                const uint32_t tt = p - W.pre[w];
-                uint32_t off = W.run[w][kWalkRows - 1];
-#pragma unroll
-                for (int u = kWalkRows - 2; u >= 0; --u) off = tt < W.run[w][kWalkRows + u] ? W.run[w][u] : off;
-                kk[j] = valid[j] ? tt + off : 0u;   // past the end of the sequence: a record that exists (masked below)
-                v[j] = rec[kk[j]];
-            }
-            unsigned long long db[UN];
-#pragma unroll
-            for (int j = 0; j < UN; ++j) {
-                const uint32_t w = wrow[j];
-                const double d = d2_exact(W.ax[w], W.ay[w], W.az[w], v[j].x, v[j].y, v[j].z);
-                db[j] = (d == d) ? (unsigned long long)__double_as_longlong(d) : kInfBits;   // NaN never wins (fmin's rule)
-                if (valid[j]) {
-                    // smallest and second smallest of the row so far: whatever the minimum displaces (or fails to displace)
-                    // is a candidate for second place -- every target but the final winner passes through d2 exactly once
-                    const unsigned long long old = atomicMin(&W.d1[w], db[j]);
-                    atomicMin(&W.d2[w], old > db[j] ? old : db[j]);
-                }
-            }
-            wave_sync();
-#pragma unroll
-            for (int j = 0; j < UN; ++j)
-                if (valid[j] && W.d1[wrow[j]] == db[j]) W.k1[wrow[j]] = kk[j];   // equal minima: any of them (a tie: k1 is not used)
-        }
-        wave_sync();
-        // (5) a row whose box is exhausted has finished a pass: done, or once more with a larger box
-        if (active && cz > b.cz1) {
-            const double dd1 = __longlong_as_double((long long)W.d1[lane]);
-            if (dd1 < INFINITY) {
-                dmin = dd1;
-                edge = tie_band(dd1);
-            }
-            if (b.all || b.B > edge) {
-                active = false;
-            } else {
-                r = next_radius(edge, r);
-                fresh = true;
-            }
-        }
+        if (threadIdx.x >= walkers) return;
+        i = s_walk[threadIdx.x];
+        need = setup();   // the same decision again (walking rows have written nothing), now with this row's state
     }
     if (!need) return;
-    const double d1 = __longlong_as_double((long long)W.d1[lane]), d2 = __longlong_as_double((long long)W.d2[lane]);
-    const uint32_t k1 = W.k1[lane];
+    double r = first_radius(g, ax, ay, az, amax, edge);
+    unsigned evals = 0;
+    bool defer = false;
+    // Keys (two square roots each) are not needed to find the winner of a pass: d1 / d2 = the smallest and the second
+    // smallest d^2 met, k1 = where the smallest sits.  With d2 outside the tie band of d1 that target has the strictly
+    // smallest key; only otherwise (near-ties, duplicated targets, lattices) the box is walked once more, comparing
+    // (key, index) among the targets inside the band -- which are the only ones that can hold the smallest key.
+    double d1 = INFINITY, d2 = INFINITY, Bfinal = 0.0;
+    uint32_t k1 = 0;
+    Box b;
+    for (;;) {
+        b = make_box(g, ax, ay, az, r);
+        d1 = INFINITY;     // every pass meets every target of its box exactly once, the seed included
+        d2 = INFINITY;
+        Bfinal = b.all ? INFINITY : b.B;
+        if (ovf_list) {
+            // A large box is handed over when it would keep this lane busy while most of its wave idles (an outlier);
+            // when most lanes of the wave have large boxes (an un-seeded pass over a scan, whose cells are mostly empty)
+            // they all walk their own, up to 16 times the caps.
+            const long rows = (long)(b.cy1 - b.cy0 + 1) * (long)(b.cz1 - b.cz0 + 1);
+            const bool big = rows > (long)row_cap;
+            const int n_big = __popcll(__ballot(big)), n_act = __popcll(__ballot(true));
+            if (big && (defer_always || rows > 16L * row_cap || 4 * n_big < n_act)) {
+                defer = true;
+                break;
+            }
+        }
+        // The cells cx0..cx1 of one (cy, cz) row are adjacent in the sorted arrays: a row is one run [k0, k1) of target
+        // records.  Rows are taken four at a time -- their eight cell-start loads go out together -- and the runs of a group
+        // are walked as ONE flattened sequence, four record loads in flight per lane: the wave then iterates max-over-lanes
+        // of (candidates / 4) times instead of once per candidate of the longest run of every row, which is what bounds
+        // this latency-bound kernel.  The visiting order changes nothing.
+        int cy = b.cy0, cz = b.cz0;
+        while (cz <= b.cz1 && !defer) {
+            uint32_t kb[ROWS], ce[ROWS], total = 0;
+#pragma unroll
+            for (int u = 0; u < ROWS; ++u) {
+                uint32_t a0 = 0, a1 = 0;
+                if (cz <= b.cz1) {
+                    const size_t row = ((size_t)cz * (size_t)g.dim[1] + (size_t)cy) * (size_t)g.dim[0];
+                    a0 = start[row + b.cx0];
+                    a1 = start[row + b.cx1 + 1];
+                    if (++cy > b.cy1) { cy = b.cy0; ++cz; }
+                }
+                kb[u] = a0;
+                total += a1 - a0;
+                ce[u] = total;
+            }
+            evals += total;
+            if (ovf_list && evals > eval_cap) {
+                const int n_big = __popcll(__ballot(true));   // lanes of the wave that are past the cap here, roughly
+                if (defer_always || evals > 16u * eval_cap || 4 * n_big < 64) {
+                    defer = true;
+                    break;
+                }
+            }
+            // position t of the flattened sequence -> sorted position: t + (offset of the run that holds t); selects, no branches
+            uint32_t o[ROWS];
+            o[0] = kb[0];
+#pragma unroll
+            for (int u = 1; u < ROWS; ++u) o[u] = kb[u] - ce[u - 1];
+            for (uint32_t t = 0; t < total; t += FLIGHT) {
+                double4 v[FLIGHT];
+                uint32_t kk[FLIGHT];
+#pragma unroll
+                for (int w = 0; w < FLIGHT; ++w) {
+                    const uint32_t tt = (t + w < total) ? t + w : t;   // past the end: a record that is met anyway (masked below)
+                    uint32_t off = o[ROWS - 1];
+#pragma unroll
+                    for (int u = ROWS - 2; u >= 0; --u) off = tt < ce[u] ? o[u] : off;
+                    kk[w] = tt + off;
+                    v[w] = rec[kk[w]];
+                }
+#pragma unroll
+                for (int w = 0; w < FLIGHT; ++w) {
+                    const double dw = d2_exact(ax, ay, az, v[w].x, v[w].y, v[w].z);
+                    const double d = (w == 0 || t + w < total) ? dw : INFINITY;
+                    d2 = __builtin_fmin(d2, __builtin_fmax(d, d1));
+                    k1 = d < d1 ? kk[w] : k1;
+                    d1 = __builtin_fmin(d1, d);
+                }
+            }
+        }
+        if (defer) break;
+        if (d1 < INFINITY) {
+            dmin = d1;
+            edge = tie_band(d1);
+        }
+        if (b.all || b.B > edge) break;
+        r = next_radius(edge, r);
+    }
     float c = 0.0f;   // the certificate of this search (header of float_below): none for near-ties and deferred rows
     if (!defer && d1 < INFINITY) {
         if (d2 > edge) {
@@ -1018,7 +926,7 @@ hipError_t search_grid(hipStream_t s, Soa3 P, size_t n, double *pc, const Grid &
     // Rows per group x loads in flight: 4 x 4.  Measured against 4 x 8, 8 x 4 and 8 x 8 (profiles/r2_v2_grid_shape_ab.txt): eight
     // loads in flight are 9-12 % slower everywhere (registers: 4 or 3 waves per SIMD instead of 5, and more masked slots),
     // eight rows per group are equal on volumes and 10 % faster only on the first searches of a 1M-point sheet.
-    hipError_t e = launch(search_grid_kernel<4>, dim3((unsigned)((n + kWG - 1) / kWG)), dim3(kWG), 0, s, P.x, P.y, P.z, pc, n, g.d, g.start, g.rec,
+    hipError_t e = launch(search_grid_kernel<4, 4>, dim3((unsigned)((n + kWG - 1) / kWG)), dim3(kWG), 0, s, P.x, P.y, P.z, pc, n, g.d, g.start, g.rec,
         Qz.x, Qz.y, Qz.z, Qz.rec, (unsigned)m, idx_prev, P.rec, order, row_cap, (unsigned)eval_cap, sc ? sc->defer_always :
         0, cnt, sc ? sc->list : nullptr, out_rec, P.rec ? motion : nullptr, order_switch, (sc && sc->stat) ? sc->stat + 2 *
         (sc->stat_slot++ % kStatSlots) : nullptr, cen_part, (unsigned)cen_chunks, cen_denom);
@@ -1037,6 +945,7 @@ hipError_t grid_scratch_alloc(hipStream_t s, size_t n, GridScratch *sc)
     sc->row_cap = getenv("ICP_AMD_GRID_ROWCAP") ? atoi(getenv("ICP_AMD_GRID_ROWCAP")) : 64;
     sc->eval_cap = getenv("ICP_AMD_GRID_EVALCAP") ? atoi(getenv("ICP_AMD_GRID_EVALCAP")) : 768;
     sc->defer_always = getenv("ICP_AMD_GRID_DEFER") && !strcmp(getenv("ICP_AMD_GRID_DEFER"), "always");
+    sc->order_switch = getenv("ICP_AMD_GRID_ORDER_SWITCH") ? atof(getenv("ICP_AMD_GRID_ORDER_SWITCH")) : 0.125;
     sc->order_switch = getenv("ICP_AMD_GRID_ORDER_SWITCH") ? atof(getenv("ICP_AMD_GRID_ORDER_SWITCH")) : 0.125;
     hipError_t e = dmalloc(&sc->count2, 2 * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMemsetAsync(sc->count2, 0, 2 * sizeof(uint32_t), s);   // s: the stream the searches will run on
