@@ -49,6 +49,19 @@ def golden(name):
     return g
 
 
+def stored_clouds(g, shape):
+    """[(iteration, running cloud the reference held at its start)] for the stored iterations after the first of an x20 fixture
+    (the first one starts from the input cloud itself)."""
+    its = [int(k) for k in g["P_in_iters"]]
+    P_in = np.asarray(g["P_in"])
+    later = [k for k in its if k > 0]
+    P_in = P_in.reshape(-1, *shape)
+    if len(P_in) == len(its):          # golden() put the input cloud back in front
+        P_in = P_in[len(its) - len(later):]
+    assert len(P_in) == len(later)
+    return list(zip(later, P_in))
+
+
 ICP_CASES = ["c1_30pts", "cow_tr1", "syn256", "syn1k", "syn3k_4k", "lattice", "syn20k", "horse_tr1", "bun045_000"]
 SMALL_ICP_CASES = ["c1_30pts", "cow_tr1", "syn256", "syn1k", "syn3k_4k", "lattice"]
 

@@ -14,7 +14,7 @@ import numpy as np
 import pytest
 
 import icp_amd
-from conftest import golden, relerr, relerr_t
+from conftest import golden, relerr, relerr_t, stored_clouds
 from icp_amd import synth
 from oracle import pyoracle as orc
 
@@ -44,9 +44,7 @@ def test_config2_sample_clouds_20_iterations(name):
     e.close()
     # stage level on the running cloud the reference itself held at iterations 2, 11 and 20
     Qz = orc.sub_row(Q, g["Qc"])
-    stored = [int(k) for k in g["P_in_iters"] if k > 0]
-    for slot, it in enumerate(stored):
-        P_in = g["P_in"].reshape(len(stored), *P.shape)[slot]
+    for it, P_in in stored_clouds(g, P.shape):
         for search in ("f32", "grid"):
             idx = icp_amd.correspondences(P_in, g["Pc"][it], Qz, search=search, q_splits=2)
             assert np.array_equal(idx, g["idx"][it]), (name, it, search)

@@ -7,7 +7,7 @@ import sys
 import numpy as np
 import pytest
 
-from conftest import ICP_CASES, golden, relerr, relerr_t
+from conftest import ICP_CASES, golden, relerr, relerr_t, stored_clouds
 from conftest import ROOT
 from oracle import pyoracle as orc
 
@@ -55,6 +55,45 @@ def test_whole_loop_against_reference(name):
     for it in range(iters):
         assert relerr_t(out["t"][it], g["t"][it], g["Qc"], g["Pc"][it]) < 1e-11
     assert relerr(out["P_out"], g["P_out"]) < 1e-11
+
+
+@pytest.mark.parametrize("name", ["bun180_000", "bun270_000", "bun315_000"])
+def test_remaining_bunny_scans_against_reference(name):
+    """data/icp's other bunny scans against bun000 (N != M), one iteration of the reference loop: the port's centroid, indices
+    and covariance bit for bit, R and t to 1e-12."""
+    g = golden(name)
+    P, Q = g["P"], golden(str(g["inputs_from"]))["Q"]
+    Qc = orc.mean0(Q)
+    assert np.array_equal(Qc, g["Qc"])
+    Pc = orc.mean0(P)
+    assert np.array_equal(Pc, g["Pc"][0])
+    Pz, Qz = orc.sub_row(P, Pc), orc.sub_row(Q, Qc)
+    idx = orc.correspondences(Pz, Qz, nthreads=NTHREADS)
+    assert np.array_equal(idx, g["idx"][0])
+    cov = orc.cross_cov(Pz, Qz, idx)
+    assert np.array_equal(cov, g["cov"][0])
+    U, S, VT = orc.svd3(cov)
+    R, t = orc.rt(U, VT, Pc, Qc)
+    assert relerr(S, g["S"][0]) < 1e-12 and relerr(R, g["R"][0]) < 1e-12 and relerr_t(t, g["t"][0], Qc, Pc) < 1e-12
+
+
+def test_second_horse_pose_against_reference():
+    """horse_tr2 -> horse_ref, 20 iterations of the reference loop: the port on the reference's own running cloud at iterations
+    1 and 11 (stage level), and its first iteration chained into the second."""
+    g = golden("horse_tr2_x20")
+    Q = golden(str(g["inputs_from"]))["Q"]
+    Qc = orc.mean0(Q)
+    assert np.array_equal(Qc, g["Qc"]) and int(g["iters"]) == 20
+    Qz = orc.sub_row(Q, Qc)
+    clouds = [(0, g["P"])] + stored_clouds(g, g["P"].shape)
+    for it, P_in in clouds:
+        Pc = orc.mean0(P_in)
+        assert np.array_equal(Pc, g["Pc"][it]), it
+        Pz = orc.sub_row(P_in, Pc)
+        idx = orc.correspondences(Pz, Qz, nthreads=NTHREADS)
+        assert np.array_equal(idx, g["idx"][it]), it
+        assert np.array_equal(orc.cross_cov(Pz, Qz, idx), g["cov"][it]), it
+        assert np.array_equal(orc.mean0(orc.apply(P_in, g["R"][it], g["t"][it])), g["Pc"][it + 1]), it   # the applied cloud's centroid
 
 
 def test_ties_against_reference():
