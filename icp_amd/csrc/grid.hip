@@ -358,9 +358,17 @@ __global__ __launch_bounds__(kWG) void search_grid_kernel(const double *__restri
                                                           uint32_t *__restrict__ ovf_list, double2 *__restrict__ out_rec,
                                                           const double *__restrict__ mot, double order_switch,
                                                           unsigned long long *__restrict__ stat,
-                                                          const double *__restrict__ cen_part, unsigned cen_chunks, double cen_denom)
+                                                          const double *__restrict__ cen_part, unsigned cen_chunks, double cen_denom,
+                                                          int xcd_map)
 {
-    const size_t l = (size_t)blockIdx.x * kWG + threadIdx.x;
+    // Workgroups go to the eight XCDs round robin (workgroup b runs on XCD b % 8), and every XCD has an L2 of its own.  The
+    // launch is a multiple of eight workgroups and XCD x takes the x-th EIGHTH of the rows -- in the spatial order a compact
+    // slab of the cloud -- so the target records and cell starts an XCD's rows walk are an eighth of the target instead of
+    // all of it (-2 % on an iteration while the clouds move).  xcd_map = 0 (ICP_AMD_GRID_XCD=0): workgroup b takes rows [256 b, 256 b + 256).
+    const unsigned per_xcd = gridDim.x >> 3;
+    const unsigned vblock = xcd_map ? (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3) : blockIdx.x;
+    const size_t l = (size_t)vblock * kWG + threadIdx.x;
+    if ((size_t)vblock * kWG >= n) return;   // the launch is rounded up to a multiple of eight (workgroup 0 always has rows)
     // The source centroid: read from pc_io, or (cen_part != nullptr, small clouds) finished here by every workgroup for
     // itself -- the fixed-order sum of the chunk partials that finalize_centroid_kernel would run as a launch of its own
     // (3.7 us of a 30 us iteration); identical code on identical inputs, so every workgroup holds the same bits, and
@@ -494,7 +502,7 @@ __global__ __launch_bounds__(kWG) void search_grid_kernel(const double *__restri
     __syncthreads();
     const uint32_t walkers = s_walkers;
     if (stat && threadIdx.x == 0) atomicAdd(&stat[0], (unsigned long long)walkers);
-    const size_t left = n - (size_t)blockIdx.x * kWG;
+    const size_t left = n - (size_t)vblock * kWG;
     if (walkers + 64 <= (left < (size_t)kWG ? left : (size_t)kWG)) {   // packing frees at least one wave
         if (threadIdx.x >= walkers) return;
         i = s_walk[threadIdx.x];
@@ -926,10 +934,12 @@ hipError_t search_grid(hipStream_t s, Soa3 P, size_t n, double *pc, const Grid &
     // Rows per group x loads in flight: 4 x 4.  Measured against 4 x 8, 8 x 4 and 8 x 8 (profiles/r2_v2_grid_shape_ab.txt): eight
     // loads in flight are 9-12 % slower everywhere (registers: 4 or 3 waves per SIMD instead of 5, and more masked slots),
     // eight rows per group are equal on volumes and 10 % faster only on the first searches of a 1M-point sheet.
-    hipError_t e = launch(search_grid_kernel<4, 4>, dim3((unsigned)((n + kWG - 1) / kWG)), dim3(kWG), 0, s, P.x, P.y, P.z, pc, n, g.d, g.start, g.rec,
+    static const int xcd_map = getenv("ICP_AMD_GRID_XCD") ? atoi(getenv("ICP_AMD_GRID_XCD")) : 1;
+    const size_t wgs_rows = (n + kWG - 1) / kWG;
+    hipError_t e = launch(search_grid_kernel<4, 4>, dim3((unsigned)(xcd_map ? (wgs_rows + 7) / 8 * 8 : wgs_rows)), dim3(kWG), 0, s, P.x, P.y, P.z, pc, n, g.d, g.start, g.rec,
         Qz.x, Qz.y, Qz.z, Qz.rec, (unsigned)m, idx_prev, P.rec, order, row_cap, (unsigned)eval_cap, sc ? sc->defer_always :
         0, cnt, sc ? sc->list : nullptr, out_rec, P.rec ? motion : nullptr, order_switch, (sc && sc->stat) ? sc->stat + 2 *
-        (sc->stat_slot++ % kStatSlots) : nullptr, cen_part, (unsigned)cen_chunks, cen_denom);
+        (sc->stat_slot++ % kStatSlots) : nullptr, cen_part, (unsigned)cen_chunks, cen_denom, xcd_map);
     if (e != hipSuccess || !sc) return e;
     size_t wgs = n < 512 ? n : 512;   // two per CU walk the queue; an empty queue (the usual case) costs the launch only
     e = launch(search_grid_overflow_kernel, dim3((unsigned)wgs), dim3(kWG), 0, s, P.x, P.y, P.z, pc, g.d, g.start, g.rec, Qz.x, Qz.y, Qz.z, Qz.rec,
