@@ -154,7 +154,8 @@ struct icp_amd_engine {
     uint32_t *order = nullptr;  // n_pad: source rows in spatial order (GRID), valid when order_ok
     bool order_ok = false;
     GridScratch gscratch;       // queue of the points the grid search hands to its overflow kernel
-    double4 *p_rec = nullptr;   // 2 * n_pad: per source row {x,y,z,idx} {matched target} (GRID: one line per query)
+    double4 *p_rec = nullptr;   // 2 * n_pad: per source row A = {x,y,z,-} in the first half, B = {matched target, idx | certificate} in the second (GRID)
+    bool soa_stale = false;     // the running cloud lives in the records' A half (apply updated only that); P.x/y/z are behind
     double2 *grid_out = nullptr;  // n_pad (key, idx) records written by the grid search
     bool use_grid = false;      // planned: search on the grid (variant/ppl/q_splits then describe the brute-force fallback)
     bool grid_auto = false;     // the grid was chosen by AUTO: fall back to brute force while most points overflow
@@ -478,17 +479,29 @@ static int plan_search(icp_amd_engine *e)
 
 // Per-source state of the grid search (overflow queue, output records, the 64-byte row records, the spatial order);
 // built from the source cloud as it is now, whenever the source or the target is replaced.
+// On the grid path with source records the transform apply updates the records' A half only; whatever reads the SoA arrays
+// (a brute-force fallback launch, the download of the cloud, a rebuild of the records) first brings them up to date.
+static int sync_soa(icp_amd_engine *e)
+{
+    if (e->soa_stale && e->P.rec && e->n) HIPCHK(source_rec_to_soa(e->stream, e->P, e->n));
+    e->soa_stale = false;
+    return ICP_AMD_OK;
+}
+
 static int prepare_grid_source(icp_amd_engine *e)
 {
     const size_t n = e->n, n_pad = e->n_pad;
+    RCCHK(sync_soa(e));   // the records are rebuilt from the SoA arrays below
     e->order_ok = false;
     e->P.rec = nullptr;
+    e->P.rec_stride = 0;
     if (n && wants_grid(e)) {
         if (!e->gscratch.list) HIPCHK(grid_scratch_alloc(e->stream, n_pad, &e->gscratch));
         if (!e->grid_out) HIPCHK(dmalloc(&e->grid_out, n_pad * sizeof(double2)));
         if (env_int("ICP_AMD_GRID_SRCREC", 1)) {
             if (!e->p_rec) HIPCHK(dmalloc(&e->p_rec, 2 * n_pad * sizeof(double4)));
             e->P.rec = e->p_rec;
+            e->P.rec_stride = n_pad;
             HIPCHK(build_source_rec(e->stream, e->P, n));
         }
         if (env_int("ICP_AMD_GRID_ORDER", 1)) {
@@ -556,6 +569,7 @@ extern "C" int icp_amd_set_source(icp_amd_engine *e, const double *P, size_t n)
         HIPCHK(hipMemcpyAsync(e->stage, P, n * 3 * sizeof(double), hipMemcpyHostToDevice, e->stream));
     }
     HIPCHK(aos_to_soa(e->stream, e->stage, n, n_pad, nullptr, 0.0, e->P));
+    e->soa_stale = false;
     RCCHK(prepare_grid_source(e));
     e->bf_left = e->bf_backoff = 0;
     HIPCHK(hipStreamSynchronize(e->stream));  // P may be reused by the caller after return
@@ -572,6 +586,7 @@ extern "C" int icp_amd_step_begin(icp_amd_engine *e)
     if (!e || !e->have_source) return fail(ICP_AMD_ESTATE, "icp_amd_step_begin: no source cloud");
     HIPCHK(set_device(e->opt.device));
     double *cen_slot = e->cen_part + (size_t)e->opt.rank * e->cpr * kCenW;
+    RCCHK(sync_soa(e));
     HIPCHK(colsum_partials(e->stream, nullptr, e->P, e->n, cen_slot));
     e->cen_ready = true;
     return ICP_AMD_OK;
@@ -630,6 +645,7 @@ extern "C" int icp_amd_step_search(icp_amd_engine *e)
             }
             if (e->bf_left) { --e->bf_left; grid = false; }
         }
+        if (!grid) RCCHK(sync_soa(e));   // the brute-force kernels and their merge read the SoA arrays
         if (!grid && !e->qrec_ok) {   // the first brute-force launch on a target that was set up for the grid
             RCCHK(bruteforce_target(e));
             choose_geometry(e);
@@ -723,7 +739,8 @@ extern "C" int icp_amd_step_update(icp_amd_engine *e)
     HIPCHK(solve(e->stream, e->cov_part, e->total_chunks, e->pc, e->qc, rejecting ? -1.0 : (double)e->n_global, e->rec,
                  e->rec + kSolveW));
     double *cen_slot = e->cen_part + (size_t)e->opt.rank * e->cpr * kCenW;
-    HIPCHK(apply(e->stream, e->P, e->n, e->rec, e->idx, cen_slot));
+    HIPCHK(apply(e->stream, e->P, e->n, e->rec, cen_slot));
+    if (e->P.rec && e->n) e->soa_stale = true;   // only the records' A half was updated
     ++e->updates_since_search;
     return ICP_AMD_OK;
 }
@@ -825,6 +842,7 @@ extern "C" int icp_amd_get_source(icp_amd_engine *e, double *P_out)
     HIPCHK(set_device(e->opt.device));
     if (e->n) {
         RCCHK(ensure_stage(e, e->n));
+        RCCHK(sync_soa(e));
         HIPCHK(soa_to_aos(e->stream, e->P, e->n, e->stage));
         HIPCHK(hipMemcpyAsync(P_out, e->stage, e->n * 3 * sizeof(double), hipMemcpyDeviceToHost, e->stream));
     }
@@ -1637,7 +1655,7 @@ extern "C" int icp_amd_apply(const double *P, size_t n, const double R[9], const
     HIPCHK(rec.alloc(sizeof h));
     HIPCHK(cen.alloc((n_pad / kChunk) * kCenW * sizeof(double)));
     HIPCHK(hipMemcpyAsync(rec.p, h, sizeof h, hipMemcpyHostToDevice, s));
-    HIPCHK(apply(s, dP, n, rec.as<double>(), nullptr, cen.as<double>()));
+    HIPCHK(apply(s, dP, n, rec.as<double>(), cen.as<double>()));
     HIPCHK(soa_to_aos(s, dP, n, pstage.as<double>()));
     HIPCHK(hipMemcpyAsync(P_out, pstage.p, n * 3 * sizeof(double), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));

@@ -352,7 +352,8 @@ __global__ __launch_bounds__(kWG) void search_grid_kernel(const double *__restri
                                                           const double *__restrict__ qz, const double4 *__restrict__ qrec4,
                                                           unsigned m,
                                                           const uint32_t *__restrict__ idx_prev,
-                                                          double4 *__restrict__ prec, const uint32_t *__restrict__ order,
+                                                          double4 *__restrict__ prec, size_t prec_stride,
+                                                          const uint32_t *__restrict__ order,
                                                           int row_cap, unsigned eval_cap, int defer_always,
                                                           uint32_t *__restrict__ ovf_count,
                                                           uint32_t *__restrict__ ovf_list, double2 *__restrict__ out_rec,
@@ -422,13 +423,13 @@ __global__ __launch_bounds__(kWG) void search_grid_kernel(const double *__restri
         js = 0xFFFFFFFFu;
         cert = 0.0; pl1 = 0.0;   // last iteration's certificate for this row; |p|_1 of the un-centred row
         if (prec) {
-            const double4 v0 = prec[2 * i], v1 = prec[2 * i + 1];
+            const double4 v0 = prec[i], v1 = prec[prec_stride + i];   // A: the row; B: its match, index | certificate
             ax = v0.x - pc[0]; ay = v0.y - pc[1]; az = v0.z - pc[2];
-            if (idx_prev) js = (uint32_t)__double_as_longlong(v0.w);
+            const unsigned long long w1 = (unsigned long long)__double_as_longlong(v1.w);
+            if (idx_prev) js = (uint32_t)w1;   // (B is kept current by whatever searched last: this kernel or merge_cov)
             sqx = v1.x; sqy = v1.y; sqz = v1.z;
             if (idx_prev && mot) {
-                const unsigned long long w1 = (unsigned long long)__double_as_longlong(v1.w);
-                if ((uint32_t)w1 == js) cert = (double)__uint_as_float((uint32_t)(w1 >> 32));   // belongs to this seed
+                cert = (double)__uint_as_float((uint32_t)(w1 >> 32));   // issued with this index by the search that wrote B
                 pl1 = (__builtin_fabs(v0.x) + __builtin_fabs(v0.y)) + __builtin_fabs(v0.z);
             }
         } else {
@@ -439,7 +440,7 @@ __global__ __launch_bounds__(kWG) void search_grid_kernel(const double *__restri
         bj = 0xFFFFFFFFu;
         amax = __builtin_fmax(__builtin_fmax(__builtin_fabs(ax), __builtin_fabs(ay)), __builtin_fabs(az));
         if (!(amax < INFINITY) || ax != ax || ay != ay || az != az) {   // every d^2 is inf or NaN: no correspondence
-            if (prec) prec[2 * i + 1] = make_double4(0.0, 0.0, 0.0, __longlong_as_double((long long)bj));
+            if (prec) prec[prec_stride + i] = make_double4(0.0, 0.0, 0.0, __longlong_as_double((long long)bj));
             else out_rec[i] = make_double2(INFINITY, __longlong_as_double((long long)bj));
             return false;
         }
@@ -483,7 +484,7 @@ __global__ __launch_bounds__(kWG) void search_grid_kernel(const double *__restri
                     const double room = sqrt(cert) * (1.0 - 0x1p-40) - delta;
                     const double lower = room > 0.0 ? (room * room) * (1.0 - 0x1p-40) : 0.0;   // every other target's new d^2 is above this
                     if (lower > edge) {
-                        prec[2 * i + 1] = make_double4(sqx, sqy, sqz, pack_idx_cert(js, float_below(lower)));
+                        prec[prec_stride + i] = make_double4(sqx, sqy, sqz, pack_idx_cert(js, float_below(lower)));
                         return false;
                     }
                 }
@@ -633,7 +634,7 @@ __global__ __launch_bounds__(kWG) void search_grid_kernel(const double *__restri
     }
     // the result (deferred: the seed, the overflow kernel starts from it): with source records, the matched target goes
     // into the second half of this row's own line -- the covariance kernel and the next search read it from there
-    if (prec) prec[2 * i + 1] = make_double4(sqx, sqy, sqz, pack_idx_cert(bj, c));
+    if (prec) prec[prec_stride + i] = make_double4(sqx, sqy, sqz, pack_idx_cert(bj, c));
     else out_rec[i] = make_double2(dmin, __longlong_as_double((long long)bj));
     if (defer) ovf_list[atomicAdd(ovf_count, 1u)] = (uint32_t)i;
     if (stat) atomicAdd(&stat[1], (unsigned long long)evals);
@@ -649,7 +650,7 @@ __global__ __launch_bounds__(kWG) void search_grid_overflow_kernel(
     const double *__restrict__ qy, const double *__restrict__ qz, const double4 *__restrict__ qrec4, unsigned m,
     const uint32_t *__restrict__ ovf_count,
     uint32_t *__restrict__ ovf_count_next, const uint32_t *__restrict__ ovf_list, uint32_t *__restrict__ host_count,
-    double4 *__restrict__ prec, double2 *__restrict__ out_rec)
+    double4 *__restrict__ prec, size_t prec_stride, double2 *__restrict__ out_rec)
 {
     __shared__ double s_d[kWG / 64], s_k[kWG / 64];
     __shared__ uint32_t s_j[kWG / 64];
@@ -661,11 +662,13 @@ __global__ __launch_bounds__(kWG) void search_grid_overflow_kernel(
     const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     for (unsigned q = blockIdx.x; q < count; q += gridDim.x) {
         const size_t i = ovf_list[q];
-        const double ax = px[i] - pc[0], ay = py[i] - pc[1], az = pz[i] - pc[2];
+        // the row: from its record where there is one (the running cloud of that path; the SoA arrays may be behind)
+        const double rx = prec ? prec[i].x : px[i], ry = prec ? prec[i].y : py[i], rz = prec ? prec[i].z : pz[i];
+        const double ax = rx - pc[0], ay = ry - pc[1], az = rz - pc[2];
         const double amax = __builtin_fmax(__builtin_fmax(__builtin_fabs(ax), __builtin_fabs(ay)), __builtin_fabs(az));
         double bk = INFINITY, dmin = INFINITY;
         uint32_t bj = 0xFFFFFFFFu;
-        const uint32_t js = (uint32_t)__double_as_longlong(prec ? prec[2 * i + 1].w : out_rec[i].y);
+        const uint32_t js = (uint32_t)__double_as_longlong(prec ? prec[prec_stride + i].w : out_rec[i].y);
         if (js < m) {
             const double d = seed_d2(ax, ay, az, js, qx, qy, qz, qrec4);
             if (d < INFINITY) {
@@ -709,12 +712,12 @@ __global__ __launch_bounds__(kWG) void search_grid_overflow_kernel(
             if (prec) {
                 double4 v = make_double4(0.0, 0.0, 0.0, 0.0);
                 if (bj < m) v = qrec4 ? qrec4[bj] : make_double4(qx[bj], qy[bj], qz[bj], 0.0);
-                prec[2 * i + 1] = make_double4(v.x, v.y, v.z, __longlong_as_double((long long)bj));
+                prec[prec_stride + i] = make_double4(v.x, v.y, v.z, __longlong_as_double((long long)(unsigned long long)bj));
             } else {
                 out_rec[i] = make_double2(bk, __longlong_as_double((long long)bj));
             }
         }
-        __syncthreads();   // prec[2i+1] / out_rec[i] may be read again if the queue lists the row twice (it does not), and
+        __syncthreads();   // the row's B record / out_rec[i] may be read again if the queue lists the row twice (it does not), and
                            // the shared scratch is reused by the next queued row
     }
 }
@@ -937,13 +940,13 @@ hipError_t search_grid(hipStream_t s, Soa3 P, size_t n, double *pc, const Grid &
     static const int xcd_map = getenv("ICP_AMD_GRID_XCD") ? atoi(getenv("ICP_AMD_GRID_XCD")) : 1;
     const size_t wgs_rows = (n + kWG - 1) / kWG;
     hipError_t e = launch(search_grid_kernel<4, 4>, dim3((unsigned)(xcd_map ? (wgs_rows + 7) / 8 * 8 : wgs_rows)), dim3(kWG), 0, s, P.x, P.y, P.z, pc, n, g.d, g.start, g.rec,
-        Qz.x, Qz.y, Qz.z, Qz.rec, (unsigned)m, idx_prev, P.rec, order, row_cap, (unsigned)eval_cap, sc ? sc->defer_always :
+        Qz.x, Qz.y, Qz.z, Qz.rec, (unsigned)m, idx_prev, P.rec, P.rec_stride, order, row_cap, (unsigned)eval_cap, sc ? sc->defer_always :
         0, cnt, sc ? sc->list : nullptr, out_rec, P.rec ? motion : nullptr, order_switch, (sc && sc->stat) ? sc->stat + 2 *
         (sc->stat_slot++ % kStatSlots) : nullptr, cen_part, (unsigned)cen_chunks, cen_denom, xcd_map);
     if (e != hipSuccess || !sc) return e;
     size_t wgs = n < 512 ? n : 512;   // two per CU walk the queue; an empty queue (the usual case) costs the launch only
     e = launch(search_grid_overflow_kernel, dim3((unsigned)wgs), dim3(kWG), 0, s, P.x, P.y, P.z, pc, g.d, g.start, g.rec, Qz.x, Qz.y, Qz.z, Qz.rec,
-                                                             (unsigned)m, cnt, cnt_next, sc->list, sc->host_count, P.rec, out_rec);
+                                                             (unsigned)m, cnt, cnt_next, sc->list, sc->host_count, P.rec, P.rec_stride, out_rec);
     sc->parity ^= 1;
     return e;
 }

@@ -55,6 +55,11 @@ struct Soa3 {            // device SoA view of a cloud
     // optional row-major copy for random access by index, rec[j] = {x, y, z, unused}: one 32-byte record (one cache
     // line touched) per gathered point instead of three
     double4 *rec = nullptr;
+    // source clouds on the grid path: rec holds TWO arrays of 32-byte halves, A[i] = rec[i] = {x, y, z, unused} and
+    // B[i] = rec[rec_stride + i] = {matched target's coordinates, idx | certificate} (grid.hip).  Two arrays rather than one
+    // 64-byte record per row: the transform apply streams A alone and the settled search reads A, B and writes B as three
+    // contiguous streams -- 11 and 14 us at 1M rows where the interleaved record measured 20 and 21 (tools/ubench_stream.hip).
+    size_t rec_stride = 0;
 };
 // rec[j] = {x[j], y[j], z[j], 0} for j < rows
 hipError_t build_rec(hipStream_t s, Soa3 soa, size_t rows);
@@ -150,8 +155,9 @@ void grid_scratch_free(GridScratch *sc);
 // sc == nullptr: every lane finishes its own point, however large its box.
 // out_rec: one {key, idx as an integer bit pattern} record per source row i < n (merge_cov's grid_rec) -- written only
 // when P.rec is not set; with P.rec the result goes into P.rec[2i+1] = {matched target's coordinates, idx}.
-// P.rec, when set, holds TWO records per source row: {x, y, z, previous idx (bit pattern)} and {coordinates of that
-// target, unused} -- everything a lane needs of its row in one 64-byte line (kept current by apply and merge_cov).
+// P.rec, when set, holds two 32-byte halves per source row (Soa3::rec_stride): A = {x, y, z, unused} -- the RUNNING cloud on
+// this path: apply updates A only, the SoA arrays are brought up to date by source_rec_to_soa when something needs them --
+// and B = {coordinates of the matched target, idx | certificate}, kept current by the search and by merge_cov.
 // motion (optional, only used with P.rec and idx_prev): the solve record (kSolveW doubles) of the rigid motion that took the
 // source rows from their position at the previous search to the present one, pc being the centroid of the moved cloud.
 // With it a row whose previous search left a certificate wide enough for that motion keeps its match without visiting a
@@ -164,8 +170,10 @@ hipError_t search_grid(hipStream_t s, Soa3 P, size_t n, double *pc, const Grid &
                        const uint32_t *idx_prev, const uint32_t *order, GridScratch *sc, double2 *out_rec,
                        const double *motion = nullptr, const double *cen_part = nullptr, size_t cen_chunks = 0,
                        double cen_denom = 1.0);
-// P.rec[2i] = {x, y, z, "no index"}, P.rec[2i+1] = 0 for i < rows
+// A[i] = {x, y, z, 0}, B[i] = {0, 0, 0, "no index"} for i < rows
 hipError_t build_source_rec(hipStream_t s, Soa3 P, size_t rows);
+// x, y, z [i] = A[i] for i < rows: the SoA arrays caught up with the running cloud of the records
+hipError_t source_rec_to_soa(hipStream_t s, Soa3 P, size_t rows);
 hipError_t grid_order(hipStream_t s, Soa3 P, size_t n, uint32_t *order);
 
 // Merge the splits (lowest index among equal keys), write idx[n], and reduce q (x) p per 1024-row chunk
@@ -190,8 +198,8 @@ constexpr int kSolveW = 28;
 hipError_t solve(hipStream_t s, const double *partial, size_t count, const double *pc, const double *qc,
                  double n_global, double *out, double *extra);
 // P <- P R^T + t (R, t read from the solve record) and per-chunk sums of the new P.
-// P.rec != nullptr: also P.rec[2i] = {new x, y, z, idx[i]}.
-hipError_t apply(hipStream_t s, Soa3 P, size_t n, const double *solve_rec, const uint32_t *idx, double *cen_partial);
+// P.rec != nullptr: the cloud that is read and written is the records' A half, and ONLY that (the SoA arrays go stale).
+hipError_t apply(hipStream_t s, Soa3 P, size_t n, const double *solve_rec, double *cen_partial);
 
 // Multi-registration mode: `batch` independent registrations of n x m points, one workgroup each, all iterations
 // on-chip.  P_in [batch][n][3], Q_in [batch][m][3] row-major; P_out same shape; rec_out [batch][kSolveW] = the

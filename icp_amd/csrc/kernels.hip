@@ -404,7 +404,7 @@ __global__ __launch_bounds__(kWG) void cov_kernel(const double *__restrict__ px,
                                                   int q_splits, const double *__restrict__ keys,
                                                   const uint32_t *__restrict__ idxs, const double2 *__restrict__ grid_rec,
                                                   const uint32_t *__restrict__ idx_in, uint32_t *__restrict__ idx_out,
-                                                  double4 *__restrict__ prec, double reject_d2,
+                                                  double4 *__restrict__ prec, size_t prec_stride, double reject_d2,
                                                   double *__restrict__ partial)
 {
     __shared__ double smem[4 * kCovW];
@@ -437,6 +437,7 @@ __global__ __launch_bounds__(kWG) void cov_kernel(const double *__restrict__ px,
             } else {
                 j = idx_in[i];
             }
+            if (MERGE && prec && !(j < m)) prec[prec_stride + i] = make_double4(0.0, 0.0, 0.0, __longlong_as_double((long long)(unsigned long long)j));
             if (j < m) {
                 const double p0 = px[i] - c0, p1 = py[i] - c1, p2 = pz[i] - c2;
                 if (qrec4) {   // one 32-byte record per gathered target
@@ -445,7 +446,8 @@ __global__ __launch_bounds__(kWG) void cov_kernel(const double *__restrict__ px,
                 } else {
                     q0 = qx[j]; q1 = qy[j]; q2 = qz[j];
                 }
-                if (MERGE && prec) prec[2 * i + 1] = make_double4(q0, q1, q2, 0.0);   // the next search's seed, next to its point
+                // the next grid search's seed: the match and its index (no certificate: this search proved no bound)
+                if (MERGE && prec) prec[prec_stride + i] = make_double4(q0, q1, q2, __longlong_as_double((long long)(unsigned long long)j));
                 // the weight hook of compute_cross_variance (src/cpu/icp.cpp:108-131: weight = kernel(p - q), a constant 1
                 // there) as a hard threshold on the pair's distance: weight 1 up to reject_d2 (+inf = the reference), else 0
                 const double d = d2_exact(p0, p1, p2, q0, q1, q2);
@@ -467,7 +469,7 @@ __global__ __launch_bounds__(kWG) void cov_kernel(const double *__restrict__ px,
 // target's coordinates and index -- sits in the row's own 64-byte record (search_grid_kernel wrote the second half), so a
 // workgroup streams 64 KB of whole lines, all of its loads in flight before the first use, and gathers nothing.  Same
 // arithmetic in the same order as cov_kernel<true>: bit-identical partials.
-__global__ __launch_bounds__(kWG) void cov_rec_kernel(const double4 *__restrict__ prec, size_t n, const double *__restrict__ pc,
+__global__ __launch_bounds__(kWG) void cov_rec_kernel(const double4 *__restrict__ prec, size_t prec_stride, size_t n, const double *__restrict__ pc,
                                                       size_t m, uint32_t *__restrict__ idx_out, double reject_d2,
                                                       double *__restrict__ partial)
 {
@@ -482,8 +484,8 @@ __global__ __launch_bounds__(kWG) void cov_rec_kernel(const double4 *__restrict_
     for (int k = 0; k < kChunk / kWG; ++k) {
         const size_t i = base + (size_t)k * kWG;
         const size_t ic = i < n ? i : n - 1;   // rows past the end: a valid address, masked below
-        a[k] = prec[2 * ic];
-        b[k] = prec[2 * ic + 1];
+        a[k] = prec[ic];
+        b[k] = prec[prec_stride + ic];
     }
 #pragma unroll
     for (int k = 0; k < kChunk / kWG; ++k) {
@@ -673,9 +675,12 @@ __device__ void solve_record(const double *tot, const double *pc, const double *
 // ------------------------------------------------------------------------------------------------
 // P_copy = P_copy.dot(R.transpose()) + t (src/cpu/icp.cpp:225): per row and output column j,
 // ((0 + x R[j][0]) + y R[j][1]) + z R[j][2], then + t[j]; un-fused.
+// REC: the running cloud is the A half of the source records (grid path): 32 bytes in, 32 bytes out per row, one stream
+// each way; the SoA arrays are not touched (they are caught up on demand, source_rec_to_soa).
+template <bool REC>
 __global__ __launch_bounds__(kWG) void apply_kernel(double *__restrict__ px, double *__restrict__ py, double *__restrict__ pz,
-                                                    size_t n, const double *__restrict__ rec, const uint32_t *__restrict__ idx,
-                                                    double4 *__restrict__ prec, double *__restrict__ cen_partial)
+                                                    size_t n, const double *__restrict__ rec, double4 *__restrict__ prec,
+                                                    double *__restrict__ cen_partial)
 {
     __shared__ double smem[4 * 3];
     const double *R = rec + 12, *t = rec + 21;
@@ -684,16 +689,20 @@ __global__ __launch_bounds__(kWG) void apply_kernel(double *__restrict__ px, dou
     double acc[3] = {0.0, 0.0, 0.0};
     const size_t base = (size_t)blockIdx.x * kChunk + threadIdx.x;
     // every load of the workgroup's four row groups goes out before the first dependent use (HBM bound: bytes in flight)
-    double lx[kChunk / kWG], ly[kChunk / kWG], lz[kChunk / kWG];
-    uint32_t lj[kChunk / kWG];
+    double lx[kChunk / kWG], ly[kChunk / kWG], lz[kChunk / kWG], lw[kChunk / kWG];
 #pragma unroll
     for (int k = 0; k < kChunk / kWG; ++k) {
         const size_t i = base + (size_t)k * kWG;
         const bool in = i < n;
-        lx[k] = in ? px[i] : 0.0;
-        ly[k] = in ? py[i] : 0.0;
-        lz[k] = in ? pz[i] : 0.0;
-        lj[k] = (in && prec) ? idx[i] : 0u;
+        if (REC) {
+            const double4 v = prec[in ? i : n - 1];
+            lx[k] = v.x; ly[k] = v.y; lz[k] = v.z; lw[k] = v.w;
+        } else {
+            lx[k] = in ? px[i] : 0.0;
+            ly[k] = in ? py[i] : 0.0;
+            lz[k] = in ? pz[i] : 0.0;
+            lw[k] = 0.0;
+        }
     }
 #pragma unroll
     for (int k = 0; k < kChunk / kWG; ++k) {
@@ -703,10 +712,13 @@ __global__ __launch_bounds__(kWG) void apply_kernel(double *__restrict__ px, dou
             const double nx = ((x * r00 + y * r01) + z * r02) + t0;
             const double ny = ((x * r10 + y * r11) + z * r12) + t1;
             const double nz = ((x * r20 + y * r21) + z * r22) + t2;
-            px[i] = nx;
-            py[i] = ny;
-            pz[i] = nz;
-            if (prec) prec[2 * i] = make_double4(nx, ny, nz, __longlong_as_double((long long)lj[k]));
+            if (REC) {
+                prec[i] = make_double4(nx, ny, nz, lw[k]);
+            } else {
+                px[i] = nx;
+                py[i] = ny;
+                pz[i] = nz;
+            }
             acc[0] += nx;
             acc[1] += ny;
             acc[2] += nz;
@@ -1104,18 +1116,37 @@ hipError_t build_rec(hipStream_t s, Soa3 soa, size_t rows)
 }
 
 __global__ __launch_bounds__(kWG) void build_source_rec_kernel(const double *__restrict__ x, const double *__restrict__ y,
-                                                               const double *__restrict__ z, size_t rows, double4 *__restrict__ rec)
+                                                               const double *__restrict__ z, size_t rows, double4 *__restrict__ rec,
+                                                               size_t stride)
 {
     const size_t i = (size_t)blockIdx.x * kWG + threadIdx.x;
     if (i >= rows) return;
-    rec[2 * i] = make_double4(x[i], y[i], z[i], __longlong_as_double(0xFFFFFFFFll));
-    rec[2 * i + 1] = make_double4(0.0, 0.0, 0.0, 0.0);
+    rec[i] = make_double4(x[i], y[i], z[i], 0.0);
+    rec[stride + i] = make_double4(0.0, 0.0, 0.0, __longlong_as_double(0xFFFFFFFFll));   // no match yet, no certificate
+}
+
+__global__ __launch_bounds__(kWG) void source_rec_to_soa_kernel(const double4 *__restrict__ rec, size_t rows, double *__restrict__ x,
+                                                                double *__restrict__ y, double *__restrict__ z)
+{
+    const size_t i = (size_t)blockIdx.x * kWG + threadIdx.x;
+    if (i >= rows) return;
+    const double4 v = rec[i];
+    x[i] = v.x;
+    y[i] = v.y;
+    z[i] = v.z;
+}
+
+hipError_t source_rec_to_soa(hipStream_t s, Soa3 P, size_t rows)
+{
+    if (rows == 0) return hipSuccess;
+    if (!P.rec) return hipErrorInvalidValue;
+    return launch(source_rec_to_soa_kernel, dim3(blocks_for(rows, kWG)), dim3(kWG), 0, s, P.rec, rows, P.x, P.y, P.z);
 }
 
 hipError_t build_source_rec(hipStream_t s, Soa3 P, size_t rows)
 {
-    if (rows == 0 || !P.rec) return hipErrorInvalidValue;
-    return launch(build_source_rec_kernel, dim3(blocks_for(rows, kWG)), dim3(kWG), 0, s, P.x, P.y, P.z, rows, P.rec);
+    if (rows == 0 || !P.rec || P.rec_stride < rows) return hipErrorInvalidValue;
+    return launch(build_source_rec_kernel, dim3(blocks_for(rows, kWG)), dim3(kWG), 0, s, P.x, P.y, P.z, rows, P.rec, P.rec_stride);
 }
 
 hipError_t soa_to_aos(hipStream_t s, Soa3 in, size_t n, double *aos)
@@ -1201,10 +1232,10 @@ hipError_t merge_cov(hipStream_t s, Soa3 P, size_t n, size_t n_pad, const double
     if (n == 0) return hipSuccess;
     if (result_in_rec && !P.rec) return hipErrorInvalidValue;
     if (result_in_rec) {
-        return launch(cov_rec_kernel, dim3(blocks_for(n, kChunk)), dim3(kWG), 0, s, P.rec, n, pc, m, idx_out, reject_d2, partial);
+        return launch(cov_rec_kernel, dim3(blocks_for(n, kChunk)), dim3(kWG), 0, s, P.rec, P.rec_stride, n, pc, m, idx_out, reject_d2, partial);
     }
     return launch(cov_kernel<true>, dim3(blocks_for(n, kChunk)), dim3(kWG), 0, s, P.x, P.y, P.z, n, n_pad, pc, Qz.x, Qz.y, Qz.z, Qz.rec, m, q_splits, keys,
-                                                           idxs, grid_rec, nullptr, idx_out, P.rec, reject_d2, partial);
+                                                           idxs, grid_rec, nullptr, idx_out, P.rec, P.rec_stride, reject_d2, partial);
 }
 
 hipError_t cov_from_idx(hipStream_t s, Soa3 P, size_t n, const double *pc, Soa3 Qz, size_t m, const uint32_t *idx,
@@ -1212,7 +1243,7 @@ hipError_t cov_from_idx(hipStream_t s, Soa3 P, size_t n, const double *pc, Soa3 
 {
     if (n == 0) return hipSuccess;
     return launch(cov_kernel<false>, dim3(blocks_for(n, kChunk)), dim3(kWG), 0, s, P.x, P.y, P.z, n, 0, pc, Qz.x, Qz.y, Qz.z, Qz.rec, m, 1, nullptr, nullptr,
-                                                            nullptr, idx, nullptr, nullptr, INFINITY, partial);
+                                                            nullptr, idx, nullptr, nullptr, (size_t)0, INFINITY, partial);
 }
 
 hipError_t solve(hipStream_t s, const double *partial, size_t count, const double *pc, const double *qc, double n_global,
@@ -1221,11 +1252,12 @@ hipError_t solve(hipStream_t s, const double *partial, size_t count, const doubl
     return launch(solve_kernel, dim3(1), dim3(kSolveWG), 0, s, partial, count, pc, qc, n_global, out, extra);
 }
 
-hipError_t apply(hipStream_t s, Soa3 P, size_t n, const double *solve_rec, const uint32_t *idx, double *cen_partial)
+hipError_t apply(hipStream_t s, Soa3 P, size_t n, const double *solve_rec, double *cen_partial)
 {
     if (n == 0) return hipSuccess;
-    if (P.rec && !idx) return hipErrorInvalidValue;
-    return launch(apply_kernel, dim3(blocks_for(n, kChunk)), dim3(kWG), 0, s, P.x, P.y, P.z, n, solve_rec, idx, P.rec, cen_partial);
+    if (P.rec)
+        return launch(apply_kernel<true>, dim3(blocks_for(n, kChunk)), dim3(kWG), 0, s, P.x, P.y, P.z, n, solve_rec, P.rec, cen_partial);
+    return launch(apply_kernel<false>, dim3(blocks_for(n, kChunk)), dim3(kWG), 0, s, P.x, P.y, P.z, n, solve_rec, P.rec, cen_partial);
 }
 
 size_t batch_lds_bytes(size_t m) { return (4 * ((m + 31) / 32 * 32) + 48 + 48) * sizeof(double); }   // the larger layout (records)
