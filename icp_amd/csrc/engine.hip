@@ -692,6 +692,7 @@ extern "C" int icp_amd_step_search(icp_amd_engine *e)
             }
         }
         const bool seeded = seed || grid_seeded;
+        GridFused fused;
         const int splits = grid ? 1 : (seeded ? e->q_splits : e->q_splits_first);
         if (!grid) RCCHK(ensure_split_buffers(e));
         if (grid) ++e->grid_launches; else ++e->bf_launches;
@@ -703,11 +704,16 @@ extern "C" int icp_amd_step_search(icp_amd_engine *e)
             e->gscratch.enabled = e->gscratch.defer_always || e->grid_since_source < 4 || *e->gscratch.host_mem > 0 ||
                                   e->grid_since_source % 16 == 0;
             ++e->grid_since_source;
-            // e->rec describes the motion since the previous search only if exactly one update ran in between
+            // e->rec describes the motion since the previous search only if exactly one update ran in between.
+            // Once the registration has settled the same launch also forms the covariance sums (grid.hip: settled search).
+            fused.idx_out = e->idx;
+            fused.reject_d2 = e->reject_d2;
+            fused.partial = cov_slot;
             HIPCHK(search_grid(e->stream, e->P, e->n, e->pc, e->grid, e->Qz, e->m, seed ? e->idx : nullptr,
                                e->order_ok ? e->order : nullptr, &e->gscratch, e->grid_out,
                                (seed && e->updates_since_search == 1 && e->grid_cert) ? e->rec : nullptr,
-                               fuse_centroid ? e->cen_part : nullptr, e->total_chunks, (double)e->n_global));
+                               fuse_centroid ? e->cen_part : nullptr, e->total_chunks, (double)e->n_global,
+                               e->P.rec ? &fused : nullptr));
         } else if (e->variant == kF32 && e->mfma16) {
             if (!e->qrec16_ok) {   // the fp16 records of this target, on first use
                 if (!e->qrec16) HIPCHK(dmalloc(&e->qrec16, 32 * e->m_pad));
@@ -723,8 +729,9 @@ extern "C" int icp_amd_step_search(icp_amd_engine *e)
             HIPCHK(search(e->stream, e->variant, e->ppl, e->cb, e->P, e->n_pad, e->pc, e->Qz, e->m, e->m_pad, splits,
                           seeded ? e->idx : nullptr, e->keys, e->idxs));
         if (e->opt.kernel_timing) HIPCHK(hipEventRecord(b, e->stream));
-        HIPCHK(merge_cov(e->stream, e->P, e->n, e->n_pad, e->pc, e->Qz, e->m, splits, e->keys, e->idxs,
-                         grid && !e->P.rec ? e->grid_out : nullptr, grid && e->P.rec, e->idx, e->reject_d2, cov_slot));
+        if (!fused.ran)
+            HIPCHK(merge_cov(e->stream, e->P, e->n, e->n_pad, e->pc, e->Qz, e->m, splits, e->keys, e->idxs,
+                             grid && !e->P.rec ? e->grid_out : nullptr, grid && e->P.rec, e->idx, e->reject_d2, cov_slot));
         e->have_prev = true;
     }
     e->updates_since_search = 0;

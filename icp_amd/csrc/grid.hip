@@ -340,41 +340,13 @@ __global__ __launch_bounds__(kWG) void grid_occupied_kernel(const uint32_t *__re
     if ((threadIdx.x & 63) == 0 && mine) atomicAdd(out, mine);
 }
 
-// One lane per source point.  A lane whose box is large (more than row_cap rows of cells or eval_cap targets -- an
-// outlier far from every target, or an un-seeded first pass) does not walk it alone while the other 63 lanes of its
-// wave wait: it records what it has found so far and queues the point for search_grid_overflow_kernel.
-template <int ROWS, int FLIGHT>   // rows of cells per group (their runs are walked as one sequence); record loads in flight per lane
-__global__ __launch_bounds__(kWG) void search_grid_kernel(const double *__restrict__ px, const double *__restrict__ py,
-                                                          const double *__restrict__ pz, double *__restrict__ pc_io, size_t n,
-                                                          GridDesc g, const uint32_t *__restrict__ start,
-                                                          const double4 *__restrict__ rec,
-                                                          const double *__restrict__ qx, const double *__restrict__ qy,
-                                                          const double *__restrict__ qz, const double4 *__restrict__ qrec4,
-                                                          unsigned m,
-                                                          const uint32_t *__restrict__ idx_prev,
-                                                          double4 *__restrict__ prec, size_t prec_stride,
-                                                          const uint32_t *__restrict__ order,
-                                                          int row_cap, unsigned eval_cap, int defer_always,
-                                                          uint32_t *__restrict__ ovf_count,
-                                                          uint32_t *__restrict__ ovf_list, double2 *__restrict__ out_rec,
-                                                          const double *__restrict__ mot, double order_switch,
-                                                          unsigned long long *__restrict__ stat,
-                                                          const double *__restrict__ cen_part, unsigned cen_chunks, double cen_denom,
-                                                          int xcd_map)
+// The source centroid of a search launch: read from pc_io, or (cen_part != nullptr, small clouds) finished here by every
+// workgroup for itself -- the fixed-order sum of the chunk partials that finalize_centroid_kernel would run as a launch of its
+// own (3.7 us of a 30 us iteration); identical code on identical inputs, so every workgroup holds the same bits, and
+// workgroup 0 publishes them for the kernels that follow.  Every thread of the workgroup must call it (barriers).
+__device__ __forceinline__ void grid_launch_centroid(double *__restrict__ pc_io, const double *__restrict__ cen_part, unsigned cen_chunks,
+                                                     double cen_denom, double pc[3])
 {
-    // Workgroups go to the eight XCDs round robin (workgroup b runs on XCD b % 8), and every XCD has an L2 of its own.  The
-    // launch is a multiple of eight workgroups and XCD x takes the x-th EIGHTH of the rows -- in the spatial order a compact
-    // slab of the cloud -- so the target records and cell starts an XCD's rows walk are an eighth of the target instead of
-    // all of it (-2 % on an iteration while the clouds move).  xcd_map = 0 (ICP_AMD_GRID_XCD=0): workgroup b takes rows [256 b, 256 b + 256).
-    const unsigned per_xcd = gridDim.x >> 3;
-    const unsigned vblock = xcd_map ? (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3) : blockIdx.x;
-    const size_t l = (size_t)vblock * kWG + threadIdx.x;
-    if ((size_t)vblock * kWG >= n) return;   // the launch is rounded up to a multiple of eight (workgroup 0 always has rows)
-    // The source centroid: read from pc_io, or (cen_part != nullptr, small clouds) finished here by every workgroup for
-    // itself -- the fixed-order sum of the chunk partials that finalize_centroid_kernel would run as a launch of its own
-    // (3.7 us of a 30 us iteration); identical code on identical inputs, so every workgroup holds the same bits, and
-    // workgroup 0 publishes them for the kernels that follow.
-    double pc[3];
     if (cen_part) {
         __shared__ double s_stage[kWG];
         __shared__ double s_pc[3];
@@ -388,128 +360,173 @@ __global__ __launch_bounds__(kWG) void search_grid_kernel(const double *__restri
     } else {
         pc[0] = pc_io[0]; pc[1] = pc_io[1]; pc[2] = pc_io[2];
     }
-    // order: source rows sorted by position, so that the lanes of a wave walk the same few cells (cache lines shared).
-    // The rows themselves stay where they are, so everything a lane needs of its row comes from one 64-byte record
-    // when the caller keeps one (prec: {x, y, z, previous index}, {that target's coordinates}).
-    // Once the registration has settled, most rows keep their match by certificate without visiting a cell, and the kernel
-    // is a stream over the row records: the rows are then taken in storage order (coalesced).  "Settled" is decided from
-    // the motion record alone -- the same value in every lane of the launch, so the launch still covers every row once --
-    // as: no point of the target's bounding volume moved by more than order_switch cell half-edges.  Either order gives
-    // the same results; this only picks the faster one.
-    bool spatial = order != nullptr;
-    if (spatial && mot && idx_prev) {
-        const double o0 = mot[25], o1 = mot[26], o2 = mot[27];
-        const double c0 = ((mot[12] * o0 + mot[13] * o1) + mot[14] * o2) + mot[21] - pc[0];
-        const double c1 = ((mot[15] * o0 + mot[16] * o1) + mot[17] * o2) + mot[22] - pc[1];
-        const double c2 = ((mot[18] * o0 + mot[19] * o1) + mot[20] * o2) + mot[23] - pc[2];
-        double rot = 0.0;
+}
+// "The registration has settled": no point of the target's bounding volume moved by more than order_switch cell half-edges in
+// the motion that mot records (the solve record of the last update; pc = the centroid after it).  Decided from the motion
+// record alone, so every lane of a launch -- and the host, one launch later -- sees the same answer.
+__device__ __forceinline__ bool grid_settled(const GridDesc &g, const double *__restrict__ mot, const double pc[3], double order_switch)
+{
+    const double o0 = mot[25], o1 = mot[26], o2 = mot[27];
+    const double c0 = ((mot[12] * o0 + mot[13] * o1) + mot[14] * o2) + mot[21] - pc[0];
+    const double c1 = ((mot[15] * o0 + mot[16] * o1) + mot[17] * o2) + mot[22] - pc[1];
+    const double c2 = ((mot[18] * o0 + mot[19] * o1) + mot[20] * o2) + mot[23] - pc[2];
+    double rot = 0.0;
 #pragma unroll
-        for (int k = 0; k < 9; ++k) {
-            const double e = mot[12 + k] - ((k % 4 == 0) ? 1.0 : 0.0);
-            rot += e * e;
-        }
-        const double ext = (g.hi[0] - g.lo[0]) + (g.hi[1] - g.lo[1]) + (g.hi[2] - g.lo[2]);
-        const double moved = sqrt(rot) * ext + ((__builtin_fabs(c0) + __builtin_fabs(c1)) + __builtin_fabs(c2));
-        spatial = !(moved <= order_switch * g.r0);   // NaN: spatial
+    for (int k = 0; k < 9; ++k) {
+        const double e = mot[12 + k] - ((k % 4 == 0) ? 1.0 : 0.0);
+        rot += e * e;
     }
-    size_t i = spatial ? order[l < n ? l : n - 1] : l;
-    double ax = 0.0, ay = 0.0, az = 0.0, sqx = 0.0, sqy = 0.0, sqz = 0.0, cert = 0.0, pl1 = 0.0, dmin = INFINITY, edge = INFINITY;
-    double delta = 0.0, amax = 0.0;   // delta: bound on how far the row moved (centred coordinates) since the previous search; 0 = unknown
-    uint32_t js = 0xFFFFFFFFu, bj = 0xFFFFFFFFu;
-    // Everything that precedes the walk over the cells, for row i: true = the row has to walk (its state is in the variables
-    // above), false = its result is written (certificate held, or no finite coordinates).
-    auto setup = [&]() -> bool {
-        sqx = sqy = sqz = 0.0;
-        js = 0xFFFFFFFFu;
-        cert = 0.0; pl1 = 0.0;   // last iteration's certificate for this row; |p|_1 of the un-centred row
-        if (prec) {
-            const double4 v0 = prec[i], v1 = prec[prec_stride + i];   // A: the row; B: its match, index | certificate
-            ax = v0.x - pc[0]; ay = v0.y - pc[1]; az = v0.z - pc[2];
-            const unsigned long long w1 = (unsigned long long)__double_as_longlong(v1.w);
-            if (idx_prev) js = (uint32_t)w1;   // (B is kept current by whatever searched last: this kernel or merge_cov)
-            sqx = v1.x; sqy = v1.y; sqz = v1.z;
-            if (idx_prev && mot) {
-                cert = (double)__uint_as_float((uint32_t)(w1 >> 32));   // issued with this index by the search that wrote B
-                pl1 = (__builtin_fabs(v0.x) + __builtin_fabs(v0.y)) + __builtin_fabs(v0.z);
-            }
-        } else {
-            ax = px[i] - pc[0]; ay = py[i] - pc[1]; az = pz[i] - pc[2];
-            if (idx_prev) js = idx_prev[i];
+    const double ext = (g.hi[0] - g.lo[0]) + (g.hi[1] - g.lo[1]) + (g.hi[2] - g.lo[2]);
+    const double moved = sqrt(rot) * ext + ((__builtin_fabs(c0) + __builtin_fabs(c1)) + __builtin_fabs(c2));
+    return moved <= order_switch * g.r0;   // NaN: not settled
+}
+
+// One lane per source point.  A lane whose box is large (more than row_cap rows of cells or eval_cap targets -- an
+// outlier far from every target, or an un-seeded first pass) does not walk it alone while the other 63 lanes of its
+// wave wait: it records what it has found so far and queues the point for search_grid_overflow_kernel.
+// What every lane of a grid search needs besides its own row: the launch's arguments and the source centroid.
+struct GridCtx {
+    const double *px, *py, *pz;
+    GridDesc g;
+    const uint32_t *start;
+    const double4 *rec;
+    const double *qx, *qy, *qz;
+    const double4 *qrec4;
+    unsigned m;
+    const uint32_t *idx_prev;
+    double4 *prec;
+    size_t prec_stride;
+    int row_cap;
+    unsigned eval_cap;
+    int defer_always;
+    uint32_t *ovf_count, *ovf_list;
+    double2 *out_rec;
+    const double *mot;
+    unsigned long long *stat;
+    double pc[3];
+};
+// One source row on its way through a search: where it is (centred), its seed / match so far, the smallest d^2 known.
+struct GridRow {
+    size_t i;
+    double ax, ay, az, sqx, sqy, sqz, dmin, edge, amax;
+    uint32_t js, bj;
+};
+#define GRID_CTX_LOCALS(c)                                                                                             \
+    const double *__restrict__ px = (c).px, *__restrict__ py = (c).py, *__restrict__ pz = (c).pz, *pc = (c).pc;      \
+    const GridDesc &g = (c).g;                                                                                         \
+    const uint32_t *__restrict__ start = (c).start;                                                                    \
+    const double4 *__restrict__ rec = (c).rec;                                                                         \
+    const double *__restrict__ qx = (c).qx, *__restrict__ qy = (c).qy, *__restrict__ qz = (c).qz;                     \
+    const double4 *__restrict__ qrec4 = (c).qrec4;                                                                     \
+    const unsigned m = (c).m;                                                                                          \
+    const uint32_t *__restrict__ idx_prev = (c).idx_prev;                                                              \
+    double4 *__restrict__ prec = (c).prec;                                                                             \
+    const size_t prec_stride = (c).prec_stride;                                                                        \
+    const int row_cap = (c).row_cap, defer_always = (c).defer_always;                                                  \
+    const unsigned eval_cap = (c).eval_cap;                                                                            \
+    uint32_t *__restrict__ ovf_count = (c).ovf_count, *__restrict__ ovf_list = (c).ovf_list;                          \
+    double2 *__restrict__ out_rec = (c).out_rec;                                                                       \
+    const double *__restrict__ mot = (c).mot;                                                                          \
+    unsigned long long *__restrict__ stat = (c).stat;                                                                  \
+    (void)px; (void)py; (void)pz; (void)pc; (void)g; (void)start; (void)rec; (void)qx; (void)qy; (void)qz; (void)qrec4; (void)m; \
+    (void)idx_prev; (void)prec; (void)prec_stride; (void)row_cap; (void)defer_always; (void)eval_cap; (void)ovf_count;         \
+    (void)ovf_list; (void)out_rec; (void)mot; (void)stat
+#define GRID_ROW_LOCALS(r)                                                                                            \
+    const size_t i = (r).i;                                                                                            \
+    double &ax = (r).ax, &ay = (r).ay, &az = (r).az, &sqx = (r).sqx, &sqy = (r).sqy, &sqz = (r).sqz, &dmin = (r).dmin, \
+           &edge = (r).edge, &amax = (r).amax;                                                                         \
+    uint32_t &js = (r).js, &bj = (r).bj;                                                                                \
+    (void)js
+
+// Everything that precedes the walk over the cells, for row r.i: true = the row has to walk (its state is in r), false = its
+// result is written (certificate held, or no finite coordinates).  With source records the caller passes the row's two
+// halves, v0 = A[i] and v1 = B[i].
+__device__ __forceinline__ bool grid_row_setup(const GridCtx &ctx, GridRow &row, const double4 v0, const double4 v1)
+{
+    GRID_CTX_LOCALS(ctx);
+    GRID_ROW_LOCALS(row);
+    double cert = 0.0, pl1 = 0.0, delta = 0.0;   // delta: bound on how far the row moved (centred coordinates) since the previous search; 0 = unknown
+    (void)delta;
+    sqx = sqy = sqz = 0.0;
+    js = 0xFFFFFFFFu;
+    cert = 0.0; pl1 = 0.0;   // last iteration's certificate for this row; |p|_1 of the un-centred row
+    if (prec) {
+        // v0 = A[i]: the row; v1 = B[i]: its match, index | certificate (loaded by the caller)
+        ax = v0.x - pc[0]; ay = v0.y - pc[1]; az = v0.z - pc[2];
+        const unsigned long long w1 = (unsigned long long)__double_as_longlong(v1.w);
+        if (idx_prev) js = (uint32_t)w1;   // (B is kept current by whatever searched last: this kernel or merge_cov)
+        sqx = v1.x; sqy = v1.y; sqz = v1.z;
+        if (idx_prev && mot) {
+            cert = (double)__uint_as_float((uint32_t)(w1 >> 32));   // issued with this index by the search that wrote B
+            pl1 = (__builtin_fabs(v0.x) + __builtin_fabs(v0.y)) + __builtin_fabs(v0.z);
         }
-        dmin = INFINITY;   // oracle: min_dist = DBL_MAX on the key, idx = -1
-        bj = 0xFFFFFFFFu;
-        amax = __builtin_fmax(__builtin_fmax(__builtin_fabs(ax), __builtin_fabs(ay)), __builtin_fabs(az));
-        if (!(amax < INFINITY) || ax != ax || ay != ay || az != az) {   // every d^2 is inf or NaN: no correspondence
-            if (prec) prec[prec_stride + i] = make_double4(0.0, 0.0, 0.0, __longlong_as_double((long long)bj));
-            else out_rec[i] = make_double2(INFINITY, __longlong_as_double((long long)bj));
-            return false;
+    } else {
+        ax = px[i] - pc[0]; ay = py[i] - pc[1]; az = pz[i] - pc[2];
+        if (idx_prev) js = idx_prev[i];
+    }
+    dmin = INFINITY;   // oracle: min_dist = DBL_MAX on the key, idx = -1
+    bj = 0xFFFFFFFFu;
+    amax = __builtin_fmax(__builtin_fmax(__builtin_fabs(ax), __builtin_fabs(ay)), __builtin_fabs(az));
+    if (!(amax < INFINITY) || ax != ax || ay != ay || az != az) {   // every d^2 is inf or NaN: no correspondence
+        if (prec) prec[prec_stride + i] = make_double4(0.0, 0.0, 0.0, __longlong_as_double((long long)bj));
+        else out_rec[i] = make_double2(INFINITY, __longlong_as_double((long long)bj));
+        return false;
+    }
+    if (!prec && js < m) {   // the coordinates of the seed
+        sqx = qrec4 ? qrec4[js].x : qx[js];
+        sqy = qrec4 ? qrec4[js].y : qy[js];
+        sqz = qrec4 ? qrec4[js].z : qz[js];
+    }
+    if (js < m) {
+        const double d = d2_exact(ax, ay, az, sqx, sqy, sqz);
+        if (d < INFINITY) {
+            dmin = d;
+            bj = js;
         }
-        if (!prec && js < m) {   // the coordinates of the seed
-            sqx = qrec4 ? qrec4[js].x : qx[js];
-            sqy = qrec4 ? qrec4[js].y : qy[js];
-            sqz = qrec4 ? qrec4[js].z : qz[js];
-        }
-        if (js < m) {
-            const double d = d2_exact(ax, ay, az, sqx, sqy, sqz);
-            if (d < INFINITY) {
-                dmin = d;
-                bj = js;
-            }
-        }
-        edge = dmin < INFINITY ? tie_band(dmin) : INFINITY;
-        delta = 0.0;
-        if (mot && idx_prev && bj == js && js < m) {
-            // The engine moved every row by p' = fl(R p + t) and re-centred: a' = R a + c + e with c = R Pc + t - Pc' and e the
-            // rounding of the transform and of the two centrings (<= 8u of the magnitudes involved; 2^-48 = 32u is charged).
-            // R is orthogonal up to the defect the solve kernel measured (mot[kSolveW + 3] = |R^T R - I|_F, required < 2^-42), so
-            // a = R^T (a' - c - e) up to 2^-40 (|a'| + |c|), and the row moved by  a' - a = (I - R^T) a' + R^T (c + e):
-            //     |a' - a| <= |(I - R^T) a'| + |c| + eps.
-            // mot = the solve record of that motion: R at [12..20], t at [21..23], the old Pc at [25..27]; pc = the new centroid.
-            const double o0 = mot[25], o1 = mot[26], o2 = mot[27], t0 = mot[21], t1 = mot[22], t2 = mot[23];
-            const double c0 = ((mot[12] * o0 + mot[13] * o1) + mot[14] * o2) + t0 - pc[0];
-            const double c1 = ((mot[15] * o0 + mot[16] * o1) + mot[17] * o2) + t1 - pc[1];
-            const double c2 = ((mot[18] * o0 + mot[19] * o1) + mot[20] * o2) + t2 - pc[2];
-            const double cn = (__builtin_fabs(c0) + __builtin_fabs(c1)) + __builtin_fabs(c2);          // >= |c|_2
-            const double mag = pl1 + ((__builtin_fabs(t0) + __builtin_fabs(t1)) + __builtin_fabs(t2)) +
-                               ((__builtin_fabs(o0) + __builtin_fabs(o1)) + __builtin_fabs(o2)) +
-                               ((__builtin_fabs(pc[0]) + __builtin_fabs(pc[1])) + __builtin_fabs(pc[2]));
-            const double al1 = (__builtin_fabs(ax) + __builtin_fabs(ay)) + __builtin_fabs(az);          // >= |a'|_2
-            // (I - R^T) a': row k of R^T is column k of R
-            const double m0 = ax - ((mot[12] * ax + mot[15] * ay) + mot[18] * az);
-            const double m1 = ay - ((mot[13] * ax + mot[16] * ay) + mot[19] * az);
-            const double m2 = az - ((mot[14] * ax + mot[17] * ay) + mot[20] * az);
-            if (mot[kSolveW + 3] < 0x1p-42) {
-                delta = (sqrt((m0 * m0 + m1 * m1) + m2 * m2) + cn) * (1.0 + 0x1p-40) + 0x1p-40 * (al1 + cn) + 0x1p-48 * mag;
-                if (cert > 0.0) {
-                    const double room = sqrt(cert) * (1.0 - 0x1p-40) - delta;
-                    const double lower = room > 0.0 ? (room * room) * (1.0 - 0x1p-40) : 0.0;   // every other target's new d^2 is above this
-                    if (lower > edge) {
-                        prec[prec_stride + i] = make_double4(sqx, sqy, sqz, pack_idx_cert(js, float_below(lower)));
-                        return false;
-                    }
+    }
+    edge = dmin < INFINITY ? tie_band(dmin) : INFINITY;
+    delta = 0.0;
+    if (mot && idx_prev && bj == js && js < m) {
+        // The engine moved every row by p' = fl(R p + t) and re-centred: a' = R a + c + e with c = R Pc + t - Pc' and e the
+        // rounding of the transform and of the two centrings (<= 8u of the magnitudes involved; 2^-48 = 32u is charged).
+        // R is orthogonal up to the defect the solve kernel measured (mot[kSolveW + 3] = |R^T R - I|_F, required < 2^-42), so
+        // a = R^T (a' - c - e) up to 2^-40 (|a'| + |c|), and the row moved by  a' - a = (I - R^T) a' + R^T (c + e):
+        //     |a' - a| <= |(I - R^T) a'| + |c| + eps.
+        // mot = the solve record of that motion: R at [12..20], t at [21..23], the old Pc at [25..27]; pc = the new centroid.
+        const double o0 = mot[25], o1 = mot[26], o2 = mot[27], t0 = mot[21], t1 = mot[22], t2 = mot[23];
+        const double c0 = ((mot[12] * o0 + mot[13] * o1) + mot[14] * o2) + t0 - pc[0];
+        const double c1 = ((mot[15] * o0 + mot[16] * o1) + mot[17] * o2) + t1 - pc[1];
+        const double c2 = ((mot[18] * o0 + mot[19] * o1) + mot[20] * o2) + t2 - pc[2];
+        const double cn = (__builtin_fabs(c0) + __builtin_fabs(c1)) + __builtin_fabs(c2);          // >= |c|_2
+        const double mag = pl1 + ((__builtin_fabs(t0) + __builtin_fabs(t1)) + __builtin_fabs(t2)) +
+                           ((__builtin_fabs(o0) + __builtin_fabs(o1)) + __builtin_fabs(o2)) +
+                           ((__builtin_fabs(pc[0]) + __builtin_fabs(pc[1])) + __builtin_fabs(pc[2]));
+        const double al1 = (__builtin_fabs(ax) + __builtin_fabs(ay)) + __builtin_fabs(az);          // >= |a'|_2
+        // (I - R^T) a': row k of R^T is column k of R
+        const double m0 = ax - ((mot[12] * ax + mot[15] * ay) + mot[18] * az);
+        const double m1 = ay - ((mot[13] * ax + mot[16] * ay) + mot[19] * az);
+        const double m2 = az - ((mot[14] * ax + mot[17] * ay) + mot[20] * az);
+        if (mot[kSolveW + 3] < 0x1p-42) {
+            delta = (sqrt((m0 * m0 + m1 * m1) + m2 * m2) + cn) * (1.0 + 0x1p-40) + 0x1p-40 * (al1 + cn) + 0x1p-48 * mag;
+            if (cert > 0.0) {
+                const double room = sqrt(cert) * (1.0 - 0x1p-40) - delta;
+                const double lower = room > 0.0 ? (room * room) * (1.0 - 0x1p-40) : 0.0;   // every other target's new d^2 is above this
+                if (lower > edge) {
+                    prec[prec_stride + i] = make_double4(sqx, sqy, sqz, pack_idx_cert(js, float_below(lower)));
+                    return false;
                 }
             }
         }
-        return true;
-    };
-    // Rows that walk are rare once certificates hold, but nearly every wave has a few, and a wave is as slow as its slowest
-    // lane: the workgroup gathers its walking rows and packs them into as few waves as they need; the other waves leave.
-    __shared__ uint32_t s_walk[kWG];
-    __shared__ uint32_t s_walkers;
-    if (threadIdx.x == 0) s_walkers = 0;
-    __syncthreads();
-    bool need = l < n && setup();
-    if (need) s_walk[atomicAdd(&s_walkers, 1u)] = (uint32_t)i;
-    __syncthreads();
-    const uint32_t walkers = s_walkers;
-    if (stat && threadIdx.x == 0) atomicAdd(&stat[0], (unsigned long long)walkers);
-    const size_t left = n - (size_t)vblock * kWG;
-    if (walkers + 64 <= (left < (size_t)kWG ? left : (size_t)kWG)) {   // packing frees at least one wave
-        if (threadIdx.x >= walkers) return;
-        i = s_walk[threadIdx.x];
-        need = setup();   // the same decision again (walking rows have written nothing), now with this row's state
     }
-    if (!need) return;
+    return true;
+}
+
+// The walk over the cells for a row that grid_row_setup() left to walk; ends with the row's result written.
+template <int ROWS, int FLIGHT>   // rows of cells per group (their runs are walked as one sequence); record loads in flight per lane
+__device__ __forceinline__ void grid_row_walk(const GridCtx &ctx, GridRow &row)
+{
+    GRID_CTX_LOCALS(ctx);
+    GRID_ROW_LOCALS(row);
     double r = first_radius(g, ax, ay, az, amax, edge);
     unsigned evals = 0;
     bool defer = false;
@@ -638,6 +655,180 @@ __global__ __launch_bounds__(kWG) void search_grid_kernel(const double *__restri
     else out_rec[i] = make_double2(dmin, __longlong_as_double((long long)bj));
     if (defer) ovf_list[atomicAdd(ovf_count, 1u)] = (uint32_t)i;
     if (stat) atomicAdd(&stat[1], (unsigned long long)evals);
+}
+
+template <int ROWS, int FLIGHT>
+__global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(5, 5))) void search_grid_kernel(const double *__restrict__ px, const double *__restrict__ py,
+                                                          const double *__restrict__ pz, double *__restrict__ pc_io, size_t n,
+                                                          GridDesc g, const uint32_t *__restrict__ start,
+                                                          const double4 *__restrict__ rec,
+                                                          const double *__restrict__ qx, const double *__restrict__ qy,
+                                                          const double *__restrict__ qz, const double4 *__restrict__ qrec4,
+                                                          unsigned m,
+                                                          const uint32_t *__restrict__ idx_prev,
+                                                          double4 *__restrict__ prec, size_t prec_stride,
+                                                          const uint32_t *__restrict__ order,
+                                                          int row_cap, unsigned eval_cap, int defer_always,
+                                                          uint32_t *__restrict__ ovf_count,
+                                                          uint32_t *__restrict__ ovf_list, double2 *__restrict__ out_rec,
+                                                          const double *__restrict__ mot, double order_switch,
+                                                          unsigned long long *__restrict__ stat,
+                                                          const double *__restrict__ cen_part, unsigned cen_chunks, double cen_denom,
+                                                          int xcd_map, uint32_t *__restrict__ settled_hint)
+{
+    // Workgroups go to the eight XCDs round robin (workgroup b runs on XCD b % 8), and every XCD has an L2 of its own.  The
+    // launch is a multiple of eight workgroups and XCD x takes the x-th EIGHTH of the rows -- in the spatial order a compact
+    // slab of the cloud -- so the target records and cell starts an XCD's rows walk are an eighth of the target instead of
+    // all of it (-2 % on an iteration while the clouds move).  xcd_map = 0 (ICP_AMD_GRID_XCD=0): workgroup b takes rows [256 b, 256 b + 256).
+    const unsigned per_xcd = gridDim.x >> 3;
+    const unsigned vblock = xcd_map ? (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3) : blockIdx.x;
+    const size_t l = (size_t)vblock * kWG + threadIdx.x;
+    if ((size_t)vblock * kWG >= n) return;   // the launch is rounded up to a multiple of eight (workgroup 0 always has rows)
+    double pc[3];
+    grid_launch_centroid(pc_io, cen_part, cen_chunks, cen_denom, pc);
+    // order: source rows sorted by position, so that the lanes of a wave walk the same few cells (cache lines shared).
+    // The rows themselves stay where they are (everything a lane needs of its row is its two record halves, when the caller
+    // keeps records).  Once the registration has settled, most rows keep their match by certificate without visiting a cell,
+    // and the kernel is a stream over the row records: the rows are then taken in storage order (coalesced).  Either order
+    // gives the same results; this only picks the faster one.
+    const bool settled = mot && idx_prev && grid_settled(g, mot, pc, order_switch);
+    const bool spatial = order != nullptr && !settled;
+    if (settled_hint && blockIdx.x == 0 && threadIdx.x == 0) *settled_hint = settled ? 1u : 0u;   // for the host's next launch
+    const size_t i = spatial ? order[l < n ? l : n - 1] : l;
+    GridCtx ctx;
+    ctx.px = px; ctx.py = py; ctx.pz = pz; ctx.g = g; ctx.start = start; ctx.rec = rec; ctx.qx = qx; ctx.qy = qy; ctx.qz = qz;
+    ctx.qrec4 = qrec4; ctx.m = m; ctx.idx_prev = idx_prev; ctx.prec = prec; ctx.prec_stride = prec_stride; ctx.row_cap = row_cap;
+    ctx.eval_cap = eval_cap; ctx.defer_always = defer_always; ctx.ovf_count = ovf_count; ctx.ovf_list = ovf_list; ctx.out_rec = out_rec;
+    ctx.mot = mot; ctx.stat = stat; ctx.pc[0] = pc[0]; ctx.pc[1] = pc[1]; ctx.pc[2] = pc[2];
+    // Rows that walk are rare once certificates hold, but nearly every wave has a few, and a wave is as slow as its slowest
+    // lane: the workgroup gathers its walking rows and packs them into as few waves as they need; the other waves leave.
+    __shared__ uint32_t s_walk[kWG];
+    __shared__ uint32_t s_walkers;
+    if (threadIdx.x == 0) s_walkers = 0;
+    __syncthreads();
+    GridRow row;
+    row.i = i;
+    auto setup = [&]() -> bool {
+        double4 v0 = make_double4(0.0, 0.0, 0.0, 0.0), v1 = v0;
+        if (prec) {
+            v0 = prec[row.i];
+            v1 = prec[prec_stride + row.i];
+        }
+        return grid_row_setup(ctx, row, v0, v1);
+    };
+    bool need = l < n && setup();
+    if (need) s_walk[atomicAdd(&s_walkers, 1u)] = (uint32_t)row.i;
+    __syncthreads();
+    const uint32_t walkers = s_walkers;
+    if (stat && threadIdx.x == 0) atomicAdd(&stat[0], (unsigned long long)walkers);
+    const size_t left = n - (size_t)vblock * kWG;
+    if (walkers + 64 <= (left < (size_t)kWG ? left : (size_t)kWG)) {   // packing frees at least one wave
+        if (threadIdx.x >= walkers) return;
+        row.i = s_walk[threadIdx.x];
+        need = setup();   // the same decision again (walking rows have written nothing), now with this row's state
+    }
+    if (need) grid_row_walk<ROWS, FLIGHT>(ctx, row);
+}
+
+// The settled registration: (nearly) every row keeps its match by certificate and the search is a stream over the row
+// records -- from whose registers the iteration's covariance can be had as well.  One workgroup per 1024-row chunk in
+// storage order, four rows per lane with all eight record loads in flight, exactly the shape of cov_rec_kernel
+// (kernels.hip), whose outputs this kernel writes too: idx_out and the chunk's partial sums, same arithmetic in the same
+// order, bit for bit.  A launch of this kernel therefore replaces search_grid_kernel AND cov_rec_kernel (64 of an
+// iteration's 228 bytes per row, and a launch).  Rows whose certificate does not hold walk the cells as in
+// search_grid_kernel (the workgroup's lanes share them out; nothing is handed to the overflow kernel: ctx.ovf_list is null),
+// and the lanes that own those rows read the results back before the sums are formed.  The host launches it when the previous
+// search reported a settled registration (a mapped word, possibly a launch old): the choice never changes a result.
+template <int ROWS, int FLIGHT>
+__global__ __launch_bounds__(kWG) void search_grid_settled_kernel(GridCtx ctx_in, double *__restrict__ pc_io, size_t n,
+                                                                  const double *__restrict__ cen_part, unsigned cen_chunks, double cen_denom,
+                                                                  double order_switch, uint32_t *__restrict__ settled_hint,
+                                                                  uint32_t *__restrict__ idx_out, double reject_d2,
+                                                                  double *__restrict__ partial)
+{
+    __shared__ double smem[4 * kCovW];
+    __shared__ uint32_t s_walk[kChunk];
+    __shared__ uint32_t s_walkers;
+    GridCtx ctx = ctx_in;
+    grid_launch_centroid(pc_io, cen_part, cen_chunks, cen_denom, ctx.pc);
+    if (settled_hint && blockIdx.x == 0 && threadIdx.x == 0)
+        *settled_hint = grid_settled(ctx.g, ctx.mot, ctx.pc, order_switch) ? 1u : 0u;
+    if (threadIdx.x == 0) s_walkers = 0;
+    double4 *__restrict__ prec = ctx.prec;
+    const size_t stride = ctx.prec_stride;
+    const size_t base = (size_t)blockIdx.x * kChunk + threadIdx.x;
+    constexpr int PER = kChunk / kWG;
+    double4 v0[PER], v1[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const size_t i = base + (size_t)k * kWG, ic = i < n ? i : n - 1;   // rows past the end: a valid address, masked below
+        v0[k] = prec[ic];
+        v1[k] = prec[stride + ic];
+    }
+    __syncthreads();
+    // what the sums need of a row: p = A - pc as cov_rec_kernel forms it, q = the matched target, j = its index
+    double p[PER][3], q[PER][3];
+    uint32_t jm[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        GridRow row;
+        row.i = base + (size_t)k * kWG;
+        const bool need = row.i < n && grid_row_setup(ctx, row, v0[k], v1[k]);
+        if (need) s_walk[atomicAdd(&s_walkers, 1u)] = (uint32_t)row.i;
+        p[k][0] = row.ax; p[k][1] = row.ay; p[k][2] = row.az;
+        q[k][0] = row.sqx; q[k][1] = row.sqy; q[k][2] = row.sqz;
+        jm[k] = row.bj;   // certificate held: the seed; no finite coordinates: none
+    }
+    __syncthreads();
+    const uint32_t walkers = s_walkers;   // the same in every lane
+    if (ctx.stat && threadIdx.x == 0) atomicAdd(&ctx.stat[0], (unsigned long long)walkers);
+    if (walkers) {
+        for (uint32_t w = threadIdx.x; w < walkers; w += kWG) {
+            GridRow wr;
+            wr.i = s_walk[w];
+            if (grid_row_setup(ctx, wr, prec[wr.i], prec[stride + wr.i])) grid_row_walk<ROWS, FLIGHT>(ctx, wr);
+        }
+        __threadfence();   // the walked rows' results have reached the L2 ...
+        __syncthreads();   // ... before the lanes that own those rows read them (past their L1, where the old line may sit).
+        // Nothing of the rows was kept in registers across the walk: a workgroup that had to walk reads its chunk again.
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const size_t i = base + (size_t)k * kWG, ic = i < n ? i : n - 1;
+            const double4 a = prec[ic];
+            const double *b = (const double *)&prec[stride + ic];
+            p[k][0] = a.x - ctx.pc[0]; p[k][1] = a.y - ctx.pc[1]; p[k][2] = a.z - ctx.pc[2];
+            q[k][0] = __hip_atomic_load(b + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            q[k][1] = __hip_atomic_load(b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            q[k][2] = __hip_atomic_load(b + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            jm[k] = (uint32_t)__hip_atomic_load((const unsigned long long *)(b + 3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    // cov_rec_kernel's sums, in its order
+    double acc[kCovW];
+#pragma unroll
+    for (int k = 0; k < kCovW; ++k) acc[k] = 0.0;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const size_t i = base + (size_t)k * kWG;
+        if (i < n) {
+            const uint32_t j = jm[k];
+            idx_out[i] = j;
+            if (j < ctx.m) {
+                const double p0 = p[k][0], p1 = p[k][1], p2 = p[k][2];
+                const double q0 = q[k][0], q1 = q[k][1], q2 = q[k][2];
+                const double d = d2_exact(p0, p1, p2, q0, q1, q2);
+                if (d <= reject_d2) {
+                    acc[0] += q0 * p0; acc[1] += q0 * p1; acc[2] += q0 * p2;
+                    acc[3] += q1 * p0; acc[4] += q1 * p1; acc[5] += q1 * p2;
+                    acc[6] += q2 * p0; acc[7] += q2 * p1; acc[8] += q2 * p2;
+                    acc[9] += d;
+                    acc[10] += 1.0;
+                }
+            }
+        }
+    }
+    const double tot = block_sum<kCovW>(acc, smem);
+    if (threadIdx.x < kCovW) partial[(size_t)blockIdx.x * kCovW + threadIdx.x] = tot;
 }
 
 // The queued points, one workgroup each: the 256 lanes walk the box together (waves take rows of cells, lanes stride
@@ -922,8 +1113,9 @@ hipError_t grid_order(hipStream_t s, Soa3 P, size_t n, uint32_t *order)
 constexpr unsigned kStatSlots = 4096;
 hipError_t search_grid(hipStream_t s, Soa3 P, size_t n, double *pc, const Grid &g, Soa3 Qz, size_t m,
                        const uint32_t *idx_prev, const uint32_t *order, GridScratch *sc, double2 *out_rec, const double *motion,
-                       const double *cen_part, size_t cen_chunks, double cen_denom)
+                       const double *cen_part, size_t cen_chunks, double cen_denom, GridFused *fused)
 {
+    if (fused) fused->ran = false;
     if (!g.ok || m == 0 || m > 0xFFFFFFF0u) return hipErrorInvalidValue;
     if (n == 0) return hipSuccess;
     const double order_switch = sc ? sc->order_switch : 0.125;   // read from the environment once, when the scratch was allocated
@@ -931,22 +1123,38 @@ hipError_t search_grid(hipStream_t s, Soa3 P, size_t n, double *pc, const Grid &
         hipError_t ez = hipMemsetAsync(sc->stat + 2 * (sc->stat_slot % kStatSlots), 0, 2 * sizeof(unsigned long long), s);
         if (ez != hipSuccess) return ez;
     }
+    GridScratch *all = sc;   // the hints and the diagnostics do not depend on whether this launch may hand rows over
     if (sc && !sc->enabled) sc = nullptr;
     const int row_cap = sc ? sc->row_cap : 64, eval_cap = sc ? sc->eval_cap : 768;
     uint32_t *cnt = sc ? sc->count2 + sc->parity : nullptr, *cnt_next = sc ? sc->count2 + (sc->parity ^ 1) : nullptr;
+    unsigned long long *stat = (all && all->stat) ? all->stat + 2 * (all->stat_slot++ % kStatSlots) : nullptr;
+    uint32_t *hint = (all && all->host_count) ? all->host_count + 1 : nullptr;
+    if (!P.rec) motion = nullptr;   // certificates live in the source records
     // Rows per group x loads in flight: 4 x 4.  Measured against 4 x 8, 8 x 4 and 8 x 8 (profiles/r2_v2_grid_shape_ab.txt): eight
     // loads in flight are 9-12 % slower everywhere (registers: 4 or 3 waves per SIMD instead of 5, and more masked slots),
     // eight rows per group are equal on volumes and 10 % faster only on the first searches of a 1M-point sheet.
+    if (fused && fused->idx_out && fused->partial && all && all->fuse_cov && hint && all->host_mem[1] == 1u && P.rec && idx_prev && motion) {
+        GridCtx c{};
+        c.px = P.x; c.py = P.y; c.pz = P.z; c.g = g.d; c.start = g.start; c.rec = g.rec; c.qx = Qz.x; c.qy = Qz.y; c.qz = Qz.z;
+        c.qrec4 = Qz.rec; c.m = (unsigned)m; c.idx_prev = idx_prev; c.prec = P.rec; c.prec_stride = P.rec_stride; c.row_cap = row_cap;
+        c.eval_cap = (unsigned)eval_cap; c.defer_always = 0; c.ovf_count = nullptr; c.ovf_list = nullptr; c.out_rec = out_rec;
+        c.mot = motion; c.stat = stat;
+        hipError_t e = launch(search_grid_settled_kernel<4, 4>, dim3((unsigned)((n + kChunk - 1) / kChunk)), dim3(kWG), 0, s, c, pc, n,
+                              cen_part, (unsigned)cen_chunks, cen_denom, order_switch, hint, fused->idx_out, fused->reject_d2,
+                              fused->partial);
+        fused->ran = e == hipSuccess;
+        return e;   // nothing was handed to the overflow kernel: its counters are as the last launch left them (zero)
+    }
     static const int xcd_map = getenv("ICP_AMD_GRID_XCD") ? atoi(getenv("ICP_AMD_GRID_XCD")) : 1;
     const size_t wgs_rows = (n + kWG - 1) / kWG;
-    hipError_t e = launch(search_grid_kernel<4, 4>, dim3((unsigned)(xcd_map ? (wgs_rows + 7) / 8 * 8 : wgs_rows)), dim3(kWG), 0, s, P.x, P.y, P.z, pc, n, g.d, g.start, g.rec,
-        Qz.x, Qz.y, Qz.z, Qz.rec, (unsigned)m, idx_prev, P.rec, P.rec_stride, order, row_cap, (unsigned)eval_cap, sc ? sc->defer_always :
-        0, cnt, sc ? sc->list : nullptr, out_rec, P.rec ? motion : nullptr, order_switch, (sc && sc->stat) ? sc->stat + 2 *
-        (sc->stat_slot++ % kStatSlots) : nullptr, cen_part, (unsigned)cen_chunks, cen_denom, xcd_map);
+    hipError_t e = launch(search_grid_kernel<4, 4>, dim3((unsigned)(xcd_map ? (wgs_rows + 7) / 8 * 8 : wgs_rows)), dim3(kWG), 0, s, P.x, P.y,
+                          P.z, pc, n, g.d, g.start, g.rec, Qz.x, Qz.y, Qz.z, Qz.rec, (unsigned)m, idx_prev, P.rec, P.rec_stride, order,
+                          row_cap, (unsigned)eval_cap, sc ? sc->defer_always : 0, cnt, sc ? sc->list : nullptr, out_rec, motion,
+                          order_switch, stat, cen_part, (unsigned)cen_chunks, cen_denom, xcd_map, hint);
     if (e != hipSuccess || !sc) return e;
     size_t wgs = n < 512 ? n : 512;   // two per CU walk the queue; an empty queue (the usual case) costs the launch only
-    e = launch(search_grid_overflow_kernel, dim3((unsigned)wgs), dim3(kWG), 0, s, P.x, P.y, P.z, pc, g.d, g.start, g.rec, Qz.x, Qz.y, Qz.z, Qz.rec,
-                                                             (unsigned)m, cnt, cnt_next, sc->list, sc->host_count, P.rec, P.rec_stride, out_rec);
+    e = launch(search_grid_overflow_kernel, dim3((unsigned)wgs), dim3(kWG), 0, s, P.x, P.y, P.z, pc, g.d, g.start, g.rec, Qz.x, Qz.y, Qz.z,
+               Qz.rec, (unsigned)m, cnt, cnt_next, sc->list, sc->host_count, P.rec, P.rec_stride, out_rec);
     sc->parity ^= 1;
     return e;
 }
@@ -967,9 +1175,11 @@ hipError_t grid_scratch_alloc(hipStream_t s, size_t n, GridScratch *sc)
         e = dmalloc(&sc->stat, 2 * kStatSlots * sizeof(unsigned long long));
         if (e == hipSuccess) e = hipMemsetAsync(sc->stat, 0, 2 * kStatSlots * sizeof(unsigned long long), s);
     }
-    if (e == hipSuccess) e = hipHostMalloc((void **)&sc->host_mem, sizeof(uint32_t), hipHostMallocMapped);
+    sc->fuse_cov = getenv("ICP_AMD_GRID_FUSE_COV") ? atoi(getenv("ICP_AMD_GRID_FUSE_COV")) : 1;
+    if (e == hipSuccess) e = hipHostMalloc((void **)&sc->host_mem, 2 * sizeof(uint32_t), hipHostMallocMapped);
     if (e == hipSuccess) {
-        *sc->host_mem = 0;
+        sc->host_mem[0] = 0;
+        sc->host_mem[1] = 0;
         e = hipHostGetDevicePointer((void **)&sc->host_count, (void *)sc->host_mem, 0);
     }
     if (e != hipSuccess) grid_scratch_free(sc);

@@ -138,8 +138,10 @@ void grid_free(Grid *g);
 struct GridScratch {
     uint32_t *count2 = nullptr;
     uint32_t *list = nullptr;               // n entries
-    volatile uint32_t *host_mem = nullptr;  // host address
-    uint32_t *host_count = nullptr;         // device address of the same word
+    volatile uint32_t *host_mem = nullptr;  // host address: [0] the last overflow queue length, [1] 1 = the last search found the
+                                            // registration settled (hints for the host's next launch, read without synchronisation)
+    uint32_t *host_count = nullptr;         // device address of the same two words
+    int fuse_cov = 1;                       // ICP_AMD_GRID_FUSE_COV=0: never the settled search that also forms the covariance sums
     int parity = 0;
     int row_cap = 64, eval_cap = 768;       // rows of cells / targets one lane walks alone (read from the environment at allocation)
     int defer_always = 0;                   // 1: hand over every box above the caps (tests); 0: only when most of the wave would idle
@@ -166,10 +168,19 @@ void grid_scratch_free(GridScratch *sc);
 // (pc = fixed-order sum / cen_denom, the result of finalize_centroid) and workgroup 0 stores it in pc for the kernels that
 // follow; meant for clouds of up to kGridFuseCentroidChunks chunks, where that saves a launch for a 3 KB re-read per workgroup.
 constexpr size_t kGridFuseCentroidChunks = 128;
+// fused (optional): the caller offers the outputs of the merge that would follow (merge_cov with result_in_rec): with source
+// records, certificates in play and a registration that the previous search found settled, one launch then does both --
+// fused->ran says whether it did (the caller then skips merge_cov).
+struct GridFused {
+    uint32_t *idx_out = nullptr;
+    double reject_d2 = 0.0;
+    double *partial = nullptr;
+    bool ran = false;
+};
 hipError_t search_grid(hipStream_t s, Soa3 P, size_t n, double *pc, const Grid &g, Soa3 Qz, size_t m,
                        const uint32_t *idx_prev, const uint32_t *order, GridScratch *sc, double2 *out_rec,
                        const double *motion = nullptr, const double *cen_part = nullptr, size_t cen_chunks = 0,
-                       double cen_denom = 1.0);
+                       double cen_denom = 1.0, GridFused *fused = nullptr);
 // A[i] = {x, y, z, 0}, B[i] = {0, 0, 0, "no index"} for i < rows
 hipError_t build_source_rec(hipStream_t s, Soa3 P, size_t rows);
 // x, y, z [i] = A[i] for i < rows: the SoA arrays caught up with the running cloud of the records

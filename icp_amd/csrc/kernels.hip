@@ -25,33 +25,7 @@ namespace icpk {
 // ------------------------------------------------------------------------------------------------
 // reductions
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ double wave_sum(double v)
-{
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-
-// Sum NV per-thread values over the 256-thread workgroup; thread k < NV returns the total of value k.
-// smem holds 4*NV doubles.  Order: butterfly inside each wave, then waves 0..3 in order.
-template <int NV>
-__device__ __forceinline__ double block_sum(double (&v)[NV], double *smem)
-{
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-#pragma unroll
-    for (int k = 0; k < NV; ++k) {
-        double r = wave_sum(v[k]);
-        if (lane == 0) smem[w * NV + k] = r;
-    }
-    __syncthreads();
-    double tot = 0.0;
-    if (threadIdx.x < NV) {
-        const int k = threadIdx.x;
-        tot = ((smem[0 * NV + k] + smem[1 * NV + k]) + smem[2 * NV + k]) + smem[3 * NV + k];
-    }
-    return tot;
-}
-
+// wave_sum / block_sum: reduce.h (shared with grid.hip, whose settled search forms the covariance partials itself)
 __global__ __launch_bounds__(kWG) void colsum_partials_kernel(const double *__restrict__ aos, const double *__restrict__ x,
                                                               const double *__restrict__ y, const double *__restrict__ z,
                                                               size_t n, double *__restrict__ partial)

@@ -5,6 +5,34 @@
 
 namespace icpk {
 
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// Sum NV per-thread values over the 256-thread workgroup; thread k < NV returns the total of value k.
+// smem holds 4*NV doubles.  Order: butterfly inside each wave, then waves 0..3 in order.
+template <int NV>
+__device__ __forceinline__ double block_sum(double (&v)[NV], double *smem)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        double r = wave_sum(v[k]);
+        if (lane == 0) smem[w * NV + k] = r;
+    }
+    __syncthreads();
+    double tot = 0.0;
+    if (threadIdx.x < NV) {
+        const int k = threadIdx.x;
+        tot = ((smem[0 * NV + k] + smem[1 * NV + k]) + smem[2 * NV + k]) + smem[3 * NV + k];
+    }
+    return tot;
+}
+
+
 // Fixed-order sum of `count` partial records of W doubles; thread k < W ends with the total of column k.
 // Order (independent of the launch geometry and of how the records were distributed over GPUs): groups of kSumGroup
 // consecutive records are summed in index order, then the group sums are summed in index order.  Up to kSumGroup
