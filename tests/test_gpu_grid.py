@@ -398,3 +398,45 @@ def test_processing_order_of_the_rows_changes_nothing(monkeypatch):
         for it in range(12):
             assert np.array_equal(runs[0][0][it], r[0][it]), it
         assert np.array_equal(runs[0][1], r[1])
+
+
+def test_settled_search_that_also_forms_the_covariance_changes_nothing(monkeypatch):
+    """Once the previous search reports a settled registration the host launches search_grid_settled_kernel: one launch that
+    searches (certificates first, the cells for the rows whose certificate fails) AND forms the chunk sums and indices
+    cov_rec_kernel would.  Against the same engine with that launch switched off (ICP_AMD_GRID_FUSE_COV=0): indices, the
+    covariance, R, t bit for bit in every iteration and the final cloud -- on a pair that converges (few rows walk), with the
+    switch forced from the second seeded search on while the cloud still moves (most rows walk inside that kernel, and are read
+    back by the lanes that own them), with the rejection hook on, on sizes that are no multiple of the chunk, on a small cloud
+    whose search also finishes the centroid, and when the source cloud is downloaded / replaced in between (the SoA arrays are
+    caught up from the records on demand)."""
+    cases = [(synth.make_pair(70000, 65000, seed=43, angle=0.05), None, None),
+             (synth.make_pair(70000, 65000, seed=44, angle=0.3), "1e30", None),      # "settled" from the start: rows walk in the fused launch
+             (synth.make_pair(20011, 23000, seed=45, angle=0.2), "1e30", 0.05),      # + rejection of far pairs
+             (synth.make_pair(3001, 2900, seed=46, angle=0.1), "1e30", None)]
+    for (P, Q), switch, dmax in cases:
+        runs = []
+        for fuse in ("1", "0"):
+            monkeypatch.setenv("ICP_AMD_GRID_FUSE_COV", fuse)
+            if switch is None:
+                monkeypatch.delenv("ICP_AMD_GRID_ORDER_SWITCH", raising=False)
+            else:
+                monkeypatch.setenv("ICP_AMD_GRID_ORDER_SWITCH", switch)
+            e = icp_amd.Engine(search="grid")
+            e.set_target(Q)
+            e.set_source(P)
+            if dmax:
+                e.set_reject_distance(dmax)
+            hist = []
+            for it in range(14):
+                e.iterate(1)
+                last = e.get_last()
+                hist.append((last["idx"].copy(), last["cov"].copy(), last["R"].copy(), last["t"].copy(), last["rms"]))
+                if it == 6:
+                    mid = e.get_source()          # catches the SoA arrays up; the records stay the running cloud
+            runs.append((hist, mid, e.get_source(), e.last_motion()))
+            e.close()
+        a, b = runs
+        for it in range(14):
+            for x, y in zip(a[0][it], b[0][it]):
+                assert np.array_equal(x, y), (len(P), switch, it)
+        assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and a[3] == b[3]

@@ -138,6 +138,49 @@ static std::vector<Half8> random_halves(size_t n, bool zeros)
     return v;
 }
 
+// Operands shaped like the kernel's (round 3, the two leads of DESIGN section 9): target records {Txh,Txh,Txl,0,Tyh,Tyh,Tyl,0} /
+// {Tzh,Tzh,Tzl,0,W0,W1,0,0} with T = -2 sigma q in hi + lo fp16 pieces and W = sigma^2 |q|^2 in two, source records
+// {xh,xl,xh,0,yh,yl,yh,0} / {zh,zl,zh,0,1,1,0,0}; coordinates uniform in the scaled range (largest 2^7).
+//   pattern 1: as the kernel builds them          pattern 2: the target's lo pieces (Txl, Tyl, Tzl, W1) zero
+//   pattern 3: both clouds shifted so that every coordinate is positive (one sign for T, one for P)      pattern 4: 2 and 3
+static int g_pattern = 0;
+static void split16h(double v, _Float16 &hi, _Float16 &lo)
+{
+    hi = (_Float16)(float)v;
+    lo = (_Float16)(float)(v - (double)(float)hi);
+}
+static double urand(double lo, double hi) { return lo + (hi - lo) * ((double)rand() / ((double)RAND_MAX + 1.0)); }
+static std::vector<Half8> kernel_halves(size_t n, bool target, int pattern)
+{
+    // first half of the array = "half 0" records (x, y), second half = "half 1" records (z, W / ones), like rec16
+    std::vector<Half8> v(n);
+    const bool nolo = pattern == 2 || pattern == 4, onesign = pattern == 3 || pattern == 4;
+    const _Float16 zero = (_Float16)0.0f, one = (_Float16)1.0f;
+    for (size_t i = 0; i < n / 2; ++i) {
+        const double lo = onesign ? 0.0 : -128.0;
+        const double x = urand(lo, 128.0), y = urand(lo, 128.0), z = urand(lo, 128.0);
+        _Float16 xh, xl, yh, yl, zh, zl;
+        Half8 a, b;
+        if (target) {
+            split16h(-2.0 * x, xh, xl); split16h(-2.0 * y, yh, yl); split16h(-2.0 * z, zh, zl);
+            if (nolo) xl = yl = zl = zero;
+            const double w = (x * x + y * y) + z * z;
+            _Float16 w0, w1;
+            split16h(w, w0, w1);
+            if (nolo) w1 = zero;
+            a = Half8{{xh, xh, xl, zero, yh, yh, yl, zero}};
+            b = Half8{{zh, zh, zl, zero, w0, w1, zero, zero}};
+        } else {
+            split16h(x, xh, xl); split16h(y, yh, yl); split16h(z, zh, zl);
+            a = Half8{{xh, xl, xh, zero, yh, yl, yh, zero}};
+            b = Half8{{zh, zl, zh, zero, one, one, zero, zero}};
+        }
+        v[i] = a;
+        v[n / 2 + i] = b;
+    }
+    return v;
+}
+
 template <int MODE, int G>
 void run(const char *name, int wps, int cus, int iters, bool zeros)
 {
@@ -150,7 +193,13 @@ void run(const char *name, int wps, int cus, int iters, bool zeros)
     CHECK(hipMalloc(&rt, blocks * 8));
     CHECK(hipMalloc(&a, 2048 * sizeof(Half8)));
     CHECK(hipMalloc(&b, 4096 * sizeof(Half8)));
-    const std::vector<Half8> ha = random_halves(2048, zeros), hb = random_halves(4096, zeros);
+    // (the kernel reads ain[0..1023] as half 0 and ain[1024..2047] as half 1; a lane's B operand is half 0 or half 1 by lane)
+    const std::vector<Half8> ha = g_pattern ? kernel_halves(2048, true, g_pattern) : random_halves(2048, zeros);
+    std::vector<Half8> hb = g_pattern ? kernel_halves(4096, false, g_pattern) : random_halves(4096, zeros);
+    if (g_pattern) {   // lanes 0..31 of a wave take half-0 records, lanes 32..63 half-1 records (index = ... + tid + 64 g, mod 4096)
+        const std::vector<Half8> src = hb;
+        for (size_t i = 0; i < 4096; ++i) hb[i] = ((i & 63) < 32) ? src[i % 2048] : src[2048 + i % 2048];
+    }
     CHECK(hipMemcpy(a, ha.data(), ha.size() * sizeof(Half8), hipMemcpyHostToDevice));
     CHECK(hipMemcpy(b, hb.data(), hb.size() * sizeof(Half8), hipMemcpyHostToDevice));
     hipEvent_t e0, e1;
@@ -171,6 +220,7 @@ void run(const char *name, int wps, int cus, int iters, bool zeros)
     std::sort(hr.begin(), hr.end());
     const double clk = (double)hc[blocks / 2] / (double)hr[blocks / 2] * 0.1;   // GHz: s_memrealtime ticks at 100 MHz
     const double slots = (double)iters * 2 * G * wps;                             // MFMA slots per SIMD
+    if (g_pattern) printf("pattern %d: ", g_pattern);
     printf("%-16s G=%d waves/SIMD=%d %s wall %8.3f ms  clock %.3f GHz  cycles/MFMA-slot/SIMD %6.2f  (kernel cycles/iter/wave %7.1f)\n", name, G, wps,
            zeros ? "zeros " : "random", ms, clk, ms * 1e-3 * clk * 1e9 / slots, (double)hc[blocks / 2] / iters);
     fflush(stdout);
@@ -183,6 +233,15 @@ int main(int argc, char **argv)
     CHECK(hipGetDeviceProperties(&p, 0));
     const int cus = p.multiProcessorCount, iters = argc > 1 ? atoi(argv[1]) : 200000;
     printf("device %s  CUs %d\n", p.name, cus);
+    if (argc > 2) {   // operand patterns of the kernel: ubench_mfma <iters> patterns
+        for (int rep = 0; rep < 2; ++rep)
+            for (int pat : {0, 1, 2, 3, 4}) {
+                g_pattern = pat;
+                run<CHAIN8_CHECK, 4>("chain8+check64", 4, cus, iters, false);
+                run<MFMA_ONLY, 4>("mfma_only", 4, cus, iters, false);
+            }
+        return 0;
+    }
     for (int w : {4, 2, 1}) {
         run<MFMA_ONLY, 4>("mfma_only", w, cus, iters, false);
         run<CHAIN1, 4>("chain1", w, cus, iters, false);
