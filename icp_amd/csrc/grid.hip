@@ -311,12 +311,13 @@ __device__ __forceinline__ void consider_rec(double ax, double ay, double az, co
     }
 }
 
-// Certificate carried from one iteration to the next (grid search with source records): D2 = a lower bound on the computed
-// d^2 of EVERY target other than the matched one, at the row's centred position a of that iteration.  The next iteration
-// moves the row to a' with |a' - a| <= delta (bounded below from the rigid motion the engine applied), so every other
-// target then has a computed d^2 >= (sqrt(D2) - delta)^2 up to a few ulp; if that still clears the tie band of the matched
-// target's new d^2, the match stands -- not even a tie is possible -- and no cell is visited.  Stored as a float rounded
-// DOWN in the upper half of rec[2i+1].w (the lower half is the index); 0 = no certificate.
+// Certificate carried from one iteration to the next (grid search with source records): s = a DISTANCE such that the computed
+// d^2 of EVERY target other than the matched one is >= s^2, at the row's centred position a of that iteration.  The next
+// iteration moves the row to a' with |a' - a| <= delta (bounded from the rigid motion the engine applied), so every other
+// target then has a computed d^2 >= (s - delta)^2 up to a few ulp; if that still clears the tie band of the matched target's
+// new d^2, the match stands -- not even a tie is possible -- and no cell is visited.  Stored as a float rounded DOWN in the
+// upper half of the row's B record's last word (the lower half is the index); 0 = no certificate.  (A distance rather than
+// its square, which round 2 stored: the check that every row runs every iteration then needs no square root for it.)
 __device__ __forceinline__ float float_below(double v)
 {
     if (!(v > 0.0)) return 0.0f;
@@ -507,12 +508,20 @@ __device__ __forceinline__ bool grid_row_setup(const GridCtx &ctx, GridRow &row,
         const double m1 = ay - ((mot[13] * ax + mot[16] * ay) + mot[19] * az);
         const double m2 = az - ((mot[14] * ax + mot[17] * ay) + mot[20] * az);
         if (mot[kSolveW + 3] < 0x1p-42) {
-            delta = (sqrt((m0 * m0 + m1 * m1) + m2 * m2) + cn) * (1.0 + 0x1p-40) + 0x1p-40 * (al1 + cn) + 0x1p-48 * mag;
+            // |m|_2 from above: the 1-norm always is; the hardware's approximate square root (v_sqrt_f64: 2^29 ulp, i.e. 2^-23
+            // relative, by its specification; 2^-18 is charged) of the squared norm is the better bound wherever that sum is
+            // far from underflow.  No correctly rounded root is needed for a bound, and this one costs one instruction where
+            // the library's costs fifty -- on every row, every iteration.
+            const double mm = (m0 * m0 + m1 * m1) + m2 * m2;
+            const double m_l1 = (__builtin_fabs(m0) + __builtin_fabs(m1)) + __builtin_fabs(m2);
+            const double m_l2 = __builtin_amdgcn_sqrt(mm) * (1.0 + 0x1p-18);
+            const double mn = mm > 0x1p-900 ? __builtin_fmin(m_l1, m_l2) : m_l1;
+            delta = (mn + cn) * (1.0 + 0x1p-40) + 0x1p-40 * (al1 + cn) + 0x1p-48 * mag;
             if (cert > 0.0) {
-                const double room = sqrt(cert) * (1.0 - 0x1p-40) - delta;
-                const double lower = room > 0.0 ? (room * room) * (1.0 - 0x1p-40) : 0.0;   // every other target's new d^2 is above this
+                const double room = cert * (1.0 - 0x1p-40) - delta;   // every other target is at least this far from a'
+                const double lower = room > 0.0 ? (room * room) * (1.0 - 0x1p-40) : 0.0;   // ... so its new computed d^2 is above this
                 if (lower > edge) {
-                    prec[prec_stride + i] = make_double4(sqx, sqy, sqz, pack_idx_cert(js, float_below(lower)));
+                    prec[prec_stride + i] = make_double4(sqx, sqy, sqz, pack_idx_cert(js, float_below(room * (1.0 - 0x1p-40))));
                     return false;
                 }
             }
@@ -624,7 +633,7 @@ __device__ __forceinline__ void grid_row_walk(const GridCtx &ctx, GridRow &row)
             const double4 v = rec[k1];   // just read: the unique minimum
             bj = (uint32_t)__double_as_longlong(v.w);
             sqx = v.x; sqy = v.y; sqz = v.z;
-            if (mot) c = float_below(__builtin_fmin(d2, Bfinal));
+            if (mot) c = float_below(sqrt(__builtin_fmin(d2, Bfinal)) * (1.0 - 0x1p-50));   // a distance: s^2 <= every other target's computed d^2
         } else {
             // near-ties: (key, index) among the targets inside the band, over the same box
             double bk = INFINITY;
@@ -702,30 +711,35 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
     ctx.mot = mot; ctx.stat = stat; ctx.pc[0] = pc[0]; ctx.pc[1] = pc[1]; ctx.pc[2] = pc[2];
     // Rows that walk are rare once certificates hold, but nearly every wave has a few, and a wave is as slow as its slowest
     // lane: the workgroup gathers its walking rows and packs them into as few waves as they need; the other waves leave.
-    __shared__ uint32_t s_walk[kWG];
+    // Rows that walk are rare once certificates hold, but nearly every wave has a few, and a wave is as slow as its slowest
+    // lane: the workgroup gathers its walking rows -- with the state their lane has already computed: reading the record and
+    // deciding again was 4 us of an iteration while rows walk -- and packs them into as few waves as they need; the other
+    // waves leave.  (Packing them in the order of their search radius, so that a wave's rows have boxes of about one size,
+    // measured the same: gpurun r3q.)
+    __shared__ GridRow s_row[kWG];
     __shared__ uint32_t s_walkers;
     if (threadIdx.x == 0) s_walkers = 0;
     __syncthreads();
     GridRow row;
     row.i = i;
-    auto setup = [&]() -> bool {
+    bool need = false;
+    if (l < n) {
         double4 v0 = make_double4(0.0, 0.0, 0.0, 0.0), v1 = v0;
         if (prec) {
             v0 = prec[row.i];
             v1 = prec[prec_stride + row.i];
         }
-        return grid_row_setup(ctx, row, v0, v1);
-    };
-    bool need = l < n && setup();
-    if (need) s_walk[atomicAdd(&s_walkers, 1u)] = (uint32_t)row.i;
+        need = grid_row_setup(ctx, row, v0, v1);
+    }
+    if (need) s_row[atomicAdd(&s_walkers, 1u)] = row;
     __syncthreads();
     const uint32_t walkers = s_walkers;
     if (stat && threadIdx.x == 0) atomicAdd(&stat[0], (unsigned long long)walkers);
     const size_t left = n - (size_t)vblock * kWG;
     if (walkers + 64 <= (left < (size_t)kWG ? left : (size_t)kWG)) {   // packing frees at least one wave
         if (threadIdx.x >= walkers) return;
-        row.i = s_walk[threadIdx.x];
-        need = setup();   // the same decision again (walking rows have written nothing), now with this row's state
+        row = s_row[threadIdx.x];   // (walking rows have written nothing yet)
+        need = true;
     }
     if (need) grid_row_walk<ROWS, FLIGHT>(ctx, row);
 }
