@@ -15,13 +15,55 @@
 // hiding that.  Everything the library clears is now cleared on the stream that uses it.)
 #include "kernels.h"
 
+#include <ctype.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include <mutex>
 #include <unordered_map>
 #include <vector>
 
 namespace icpk {
+
+// ---- debugging / test switches: one list, ICP_AMD_DEBUG="name=value,name=value" (kernels.h) ----
+const char *knob(const char *name)
+{
+    static thread_local char buf[128];
+    const size_t len = strlen(name);
+    if (const char *list = getenv("ICP_AMD_DEBUG")) {
+        for (const char *p = list; *p;) {
+            while (*p == ',' || *p == ' ') ++p;
+            const char *end = strchr(p, ',');
+            const size_t item = end ? (size_t)(end - p) : strlen(p);
+            if (item > len && !strncmp(p, name, len) && p[len] == '=') {
+                size_t vl = item - len - 1;
+                while (vl && p[len + vl] == ' ') --vl;
+                if (vl >= sizeof buf) vl = sizeof buf - 1;
+                memcpy(buf, p + len + 1, vl);
+                buf[vl] = 0;
+                return buf;
+            }
+            p += item;
+        }
+    }
+    char var[96] = "ICP_AMD_";   // the switch as a variable of its own (older spelling)
+    size_t k = 8;
+    for (size_t c = 0; c < len && k + 1 < sizeof var; ++c) var[k++] = (char)toupper((unsigned char)name[c]);
+    var[k] = 0;
+    const char *v = getenv(var);
+    return (v && *v) ? v : nullptr;
+}
+int knob_int(const char *name, int dflt)
+{
+    const char *v = knob(name);
+    return v ? atoi(v) : dflt;
+}
+double knob_double(const char *name, double dflt)
+{
+    const char *v = knob(name);
+    return v ? atof(v) : dflt;
+}
+
 namespace {
 
 struct Block { void *p; size_t bytes; int dev; };
@@ -62,7 +104,7 @@ void trim_locked(int dev)
 // index, a denormal as a double -- so that code relying on fresh (zeroed) or on stale memory shows up as a wrong result.
 static hipError_t poisoned(void *p, size_t bytes)
 {
-    static const bool on = [] { const char *v = getenv("ICP_AMD_CACHE_POISON"); return v && atoi(v) != 0; }();
+    static const bool on = knob_int("cache_poison", 0) != 0;
     if (!on) return hipSuccess;
     hipError_t e = hipMemsetD32((hipDeviceptr_t)p, 3, bytes / 4);
     if (e == hipSuccess) e = hipDeviceSynchronize();

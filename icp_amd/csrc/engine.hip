@@ -374,12 +374,12 @@ static int requested_variant(const icp_amd_engine *e)
 // 32-row source groups per wave of the matrix kernel.
 static int mfma_groups(size_t n_pad)
 {
-    if (env_int("ICP_AMD_MFMA", 16) == 0) return 0;
+    if (knob_int("mfma", 16) == 0) return 0;
     // 128 source rows x groups per workgroup: small clouds need the workgroups more than the operand reuse
-    const int g = env_int("ICP_AMD_MFMA_G", n_pad < 120000 ? 2 : 4);
+    const int g = knob_int("mfma_g", n_pad < 120000 ? 2 : 4);
     return g == 2 ? 2 : 4;   // four waves per SIMD: eight groups would not fit the register file
 }
-static bool mfma_fp16() { return env_int("ICP_AMD_MFMA", 16) != 0; }
+static bool mfma_fp16() { return knob_int("mfma", 16) != 0; }
 
 // AUTO searches on the grid from this many targets on: the grid saves 18 us per iteration at 1000 targets (36 at 2000)
 // and costs about 250 us more to set up (tools/tiny_probe.py), so it pays from roughly 15 iterations on here.
@@ -410,7 +410,7 @@ static void choose_geometry(icp_amd_engine *e)
     // Source points per lane: more points share one LDS read of a target (the big clouds are LDS-read bound below 8 for
     // the fp32 filter, below 4 for fp64), fewer give more workgroups to spread a small cloud over the chip.
     int ppl = f32 ? (e->n_pad <= 32768 ? 2 : e->n_pad <= 524288 ? 4 : 8) : (e->n_pad <= 32768 ? 2 : 4);
-    const int env_ppl = env_int("ICP_AMD_PPL", 0);
+    const int env_ppl = knob_int("ppl", 0);
     if ((env_ppl == 1 && !f32) || env_ppl == 2 || env_ppl == 4 || (env_ppl == 8 && f32)) ppl = env_ppl;
     // Workgroups: each one pays a fixed price (its seed blocks, its tile loads, one record per source point and split
     // for the merge), while too few leave CUs idle at the tail -- the optimum grows like sqrt(pairs).  Measured on
@@ -427,7 +427,7 @@ static void choose_geometry(icp_amd_engine *e)
     size_t splits = (want + xblocks - 1) / xblocks;
     if (splits > 1024) splits = 1024;
     if (e->opt.q_splits > 0) splits = (size_t)e->opt.q_splits;
-    splits = (size_t)env_int("ICP_AMD_QSPLITS", (int)splits);
+    splits = (size_t)knob_int("qsplits", (int)splits);
     if (splits < 1) splits = 1;
     if (splits > scan_blocks) splits = scan_blocks;
     e->ppl = ppl;
@@ -435,7 +435,7 @@ static void choose_geometry(icp_amd_engine *e)
     // an un-seeded search re-learns its running minimum in every split: keep the first iteration coarser
     const size_t first_cap = f32 ? 8 : 16;
     e->q_splits_first = (int)(splits > first_cap ? first_cap : splits);
-    int cb = env_int("ICP_AMD_CB", 32);
+    int cb = knob_int("cb", 32);
     if (cb != 8 && cb != 16 && cb != 32) cb = 32;
     if (f32 && cb == 8) cb = 16;
     e->cb = cb;
@@ -468,9 +468,9 @@ static int plan_search(icp_amd_engine *e)
         RCCHK(bruteforce_target(e));
         choose_geometry(e);
     }
-    e->seed_enabled = env_int("ICP_AMD_SEED", 1) != 0;
-    e->grid_cert = env_int("ICP_AMD_GRID_CERT", 1) != 0;
-    e->fuse_centroid = env_int("ICP_AMD_GRID_FUSE_CENTROID", 1) != 0;
+    e->seed_enabled = knob_int("seed", 1) != 0;
+    e->grid_cert = knob_int("grid_cert", 1) != 0;
+    e->fuse_centroid = knob_int("grid_fuse_centroid", 1) != 0;
     // On the grid path the brute-force kernels are only AUTO's fallback: their scratch (12 bytes per source row and
     // target split, 0.4 GB at 1M x 1M) is then allocated by the first fallback launch instead of here.
     if (!e->use_grid) RCCHK(ensure_split_buffers(e));
@@ -498,13 +498,13 @@ static int prepare_grid_source(icp_amd_engine *e)
     if (n && wants_grid(e)) {
         if (!e->gscratch.list) HIPCHK(grid_scratch_alloc(e->stream, n_pad, &e->gscratch));
         if (!e->grid_out) HIPCHK(dmalloc(&e->grid_out, n_pad * sizeof(double2)));
-        if (env_int("ICP_AMD_GRID_SRCREC", 1)) {
+        if (knob_int("grid_srcrec", 1)) {
             if (!e->p_rec) HIPCHK(dmalloc(&e->p_rec, 2 * n_pad * sizeof(double4)));
             e->P.rec = e->p_rec;
             e->P.rec_stride = n_pad;
             HIPCHK(build_source_rec(e->stream, e->P, n));
         }
-        if (env_int("ICP_AMD_GRID_ORDER", 1)) {
+        if (knob_int("grid_order", 1)) {
             if (!e->order) HIPCHK(dmalloc(&e->order, n_pad * sizeof(uint32_t)));
             HIPCHK(grid_order(e->stream, e->P, n, e->order));
             e->order_ok = true;
@@ -661,7 +661,7 @@ extern "C" int icp_amd_step_search(icp_amd_engine *e)
         // its exact answer (0.5 ms) is that seed; the brute-force launch still evaluates every pair.  ICP_AMD_GRID_SEED=0
         // keeps the un-seeded launch (tests of that code path).
         bool grid_seeded = false;
-        if (!grid && !seed && e->seed_enabled && e->m >= kAutoGridMinTargets && !e->P.rec && env_int("ICP_AMD_GRID_SEED", 1)) {
+        if (!grid && !seed && e->seed_enabled && e->m >= kAutoGridMinTargets && !e->P.rec && knob_int("grid_seed", 1)) {
             // Best effort: the seed only makes the launch below faster.  If the grid or its scratch cannot be had (e.g. out of
             // memory beside the split buffers) the launch simply runs un-seeded; and an engine whose planned search is brute
             // force gives the grid's memory back as soon as the seed is taken (one use per source cloud).
@@ -1170,7 +1170,7 @@ extern "C" int icp_amd_run_multi(const double *P, size_t n, const double *Q, siz
                         RCCHK(icp_amd_get_last(r.eng[g], nullptr, tr->idx + (size_t)it * n + lo[g], nullptr, nullptr, nullptr, nullptr, nullptr));
         }
     }
-    if (iters && env_int("ICP_AMD_MULTI_CROSSCHECK", 0)) {
+    if (iters && knob_int("multi_crosscheck", 0)) {
         // Debug cross-check: every device solved R, t redundantly from the same gathered partials, so no
         // broadcast is needed -- but rank 0's R || t, broadcast (ncclBroadcast, or a peer copy on the RCCL-free exchange),
         // must then equal every device's own, bit for bit.  A mismatch means the exchange delivered different partials.
@@ -1446,7 +1446,7 @@ static int correspondences_impl(const double *P, size_t n, const double Pc[3], c
     const size_t max_splits = search_scan_rows(m) / kSplitGran;
     if (q_splits < 1) q_splits = 1;
     if ((size_t)q_splits > max_splits) q_splits = (int)max_splits;
-    int ppl = env_int("ICP_AMD_PPL", 4);
+    int ppl = knob_int("ppl", 4);
     if (ppl != 1 && ppl != 2 && ppl != 4 && ppl != 8) ppl = 4;
     if (f32 && ppl == 1) ppl = 2;
     if (!f32 && ppl == 8) ppl = 4;
@@ -1455,7 +1455,7 @@ static int correspondences_impl(const double *P, size_t n, const double Pc[3], c
     HIPCHK(out.alloc(n_pad * sizeof(uint32_t)));
     HIPCHK(part.alloc((n_pad / kChunk) * kCovW * sizeof(double)));
     const int variant = search_variant == ICP_AMD_SEARCH_FMA ? kFma : kExact;
-    int cb = env_int("ICP_AMD_CB", 32);
+    int cb = knob_int("cb", 32);
     if (cb != 8 && cb != 16 && cb != 32) cb = 32;
     struct GridHolder { Grid g; ~GridHolder() { grid_free(&g); } } gh;
     bool grid = search_variant == ICP_AMD_SEARCH_GRID;
@@ -1463,7 +1463,7 @@ static int correspondences_impl(const double *P, size_t n, const double Pc[3], c
         HIPCHK(grid_build(s, dQ, m, &gh.g));
         grid = gh.g.ok;   // non-finite target coordinates: brute force below, like the engine
     }
-    if (!grid && !prev && search_variant != ICP_AMD_SEARCH_GRID && m >= kAutoGridMinTargets && env_int("ICP_AMD_GRID_SEED", 1)) {
+    if (!grid && !prev && search_variant != ICP_AMD_SEARCH_GRID && m >= kAutoGridMinTargets && knob_int("grid_seed", 1)) {
         // like the engine's first iteration: the grid's exact answer seeds the brute-force scan (which still evaluates
         // every pair); targets the grid cannot file (non-finite coordinates) leave the launch un-seeded
         // best effort, like the engine: a seed that cannot be had (no memory for the grid) leaves the launch un-seeded

@@ -1086,17 +1086,15 @@ done:
     return e;
 }
 
-static double env_per_cell(const char *name, double dflt)
+static double per_cell_setting(double dflt)
 {
-    const char *v = getenv(name);
-    const double x = v ? atof(v) : 0.0;
+    const double x = knob_double("grid_per_cell", 0.0);
     return x >= 0.25 && x <= 65536.0 ? x : dflt;
 }
 
 hipError_t grid_build(hipStream_t s, Soa3 Qz, size_t m, Grid *g)
 {
-    const char *rf = getenv("ICP_AMD_GRID_REFINE");
-    return grid_sort(s, Qz, m, env_per_cell("ICP_AMD_GRID_PER_CELL", 2.0), true, !(rf && atoi(rf) == 0), g);
+    return grid_sort(s, Qz, m, per_cell_setting(2.0), true, knob_int("grid_refine", 1) != 0, g);
 }
 
 __global__ __launch_bounds__(kWG) void iota_kernel(uint32_t *out, size_t n)
@@ -1159,7 +1157,7 @@ hipError_t search_grid(hipStream_t s, Soa3 P, size_t n, double *pc, const Grid &
         fused->ran = e == hipSuccess;
         return e;   // nothing was handed to the overflow kernel: its counters are as the last launch left them (zero)
     }
-    static const int xcd_map = getenv("ICP_AMD_GRID_XCD") ? atoi(getenv("ICP_AMD_GRID_XCD")) : 1;
+    static const int xcd_map = knob_int("grid_xcd", 1);
     const size_t wgs_rows = (n + kWG - 1) / kWG;
     hipError_t e = launch(search_grid_kernel<4, 4>, dim3((unsigned)(xcd_map ? (wgs_rows + 7) / 8 * 8 : wgs_rows)), dim3(kWG), 0, s, P.x, P.y,
                           P.z, pc, n, g.d, g.start, g.rec, Qz.x, Qz.y, Qz.z, Qz.rec, (unsigned)m, idx_prev, P.rec, P.rec_stride, order,
@@ -1177,19 +1175,18 @@ hipError_t grid_scratch_alloc(hipStream_t s, size_t n, GridScratch *sc)
 {
     grid_scratch_free(sc);
     // what one lane may walk on its own before it hands its point to the overflow kernel (tunable for tests)
-    sc->row_cap = getenv("ICP_AMD_GRID_ROWCAP") ? atoi(getenv("ICP_AMD_GRID_ROWCAP")) : 64;
-    sc->eval_cap = getenv("ICP_AMD_GRID_EVALCAP") ? atoi(getenv("ICP_AMD_GRID_EVALCAP")) : 768;
-    sc->defer_always = getenv("ICP_AMD_GRID_DEFER") && !strcmp(getenv("ICP_AMD_GRID_DEFER"), "always");
-    sc->order_switch = getenv("ICP_AMD_GRID_ORDER_SWITCH") ? atof(getenv("ICP_AMD_GRID_ORDER_SWITCH")) : 0.125;
-    sc->order_switch = getenv("ICP_AMD_GRID_ORDER_SWITCH") ? atof(getenv("ICP_AMD_GRID_ORDER_SWITCH")) : 0.125;
+    sc->row_cap = knob_int("grid_rowcap", 64);
+    sc->eval_cap = knob_int("grid_evalcap", 768);
+    sc->defer_always = knob("grid_defer") && !strcmp(knob("grid_defer"), "always");
+    sc->order_switch = knob_double("grid_order_switch", 0.125);
     hipError_t e = dmalloc(&sc->count2, 2 * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMemsetAsync(sc->count2, 0, 2 * sizeof(uint32_t), s);   // s: the stream the searches will run on
     if (e == hipSuccess) e = dmalloc(&sc->list, (n ? n : 1) * sizeof(uint32_t));
-    if (e == hipSuccess && getenv("ICP_AMD_GRID_STATS") && atoi(getenv("ICP_AMD_GRID_STATS"))) {
+    if (e == hipSuccess && knob_int("grid_stats", 0)) {
         e = dmalloc(&sc->stat, 2 * kStatSlots * sizeof(unsigned long long));
         if (e == hipSuccess) e = hipMemsetAsync(sc->stat, 0, 2 * kStatSlots * sizeof(unsigned long long), s);
     }
-    sc->fuse_cov = getenv("ICP_AMD_GRID_FUSE_COV") ? atoi(getenv("ICP_AMD_GRID_FUSE_COV")) : 1;
+    sc->fuse_cov = knob_int("grid_fuse_cov", 1);
     if (e == hipSuccess) e = hipHostMalloc((void **)&sc->host_mem, 2 * sizeof(uint32_t), hipHostMallocMapped);
     if (e == hipSuccess) {
         sc->host_mem[0] = 0;

@@ -39,6 +39,15 @@ enum SearchVariant { kExact = 1, kFma = 2, kF32 = 3, kGrid = 4, kExpanded = 5 /*
 constexpr size_t kPadRows = 2048;  // clouds are padded to this many rows (covers every kernel's tile)
 constexpr size_t kSplitGran = 128; // target splits are whole multiples of this many targets (>= every kernel's event-check block)
 
+// Debugging / test switches (devmem.cpp).  The variables a user sets have names of their own -- ICP_AMD_DEVICE, ICP_AMD_SEARCH,
+// ICP_AMD_GPUS, ICP_AMD_CACHE_MB, ICP_AMD_CSV_THREADS, ICP_AMD_RESULT_FILE, ICP_AMD_MULTI_EXCHANGE, ICP_AMD_BATCH_WORKERS; every
+// other switch is an entry of ONE list, ICP_AMD_DEBUG="grid_cert=0,mfma=0,qsplits=5" (lower-case names, INTEGRATION.md has
+// the table).  The older spelling of a switch as a variable of its own, ICP_AMD_<NAME>, is still honoured (the list wins).
+// knob() returns the value's text or nullptr; none of the switches changes a result.
+const char *knob(const char *name);
+int knob_int(const char *name, int dflt);
+double knob_double(const char *name, double dflt);
+
 // Device memory through a small cache (devmem.cpp): same contracts as hipMalloc / hipFree, but released blocks are kept
 // (ICP_AMD_CACHE_MB, default 2048) and reused by later requests of about the same size.
 hipError_t dmalloc_bytes(void **p, size_t bytes);

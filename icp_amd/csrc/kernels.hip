@@ -1189,7 +1189,7 @@ hipError_t search_f32(hipStream_t s, int ppl, int cb, Soa3 P, size_t n_pad, cons
 {
     if (n_pad == 0 || m_pad == 0 || n_pad % (kWG * 8) || m_pad % kTileQF || q_splits < 1 || m > m_pad || !(qmax >= 0.0))
         return hipErrorInvalidValue;
-    static const bool pk = !(getenv("ICP_AMD_PK") && atoi(getenv("ICP_AMD_PK")) == 0);
+    static const bool pk = knob_int("pk", 1) != 0;
 #define ICPK_CASE(PPL_, CB_) \
     if (ppl == PPL_ && cb == CB_) \
         return pk ? search_f32_launch<PPL_, CB_, true>(s, P, n_pad, pc, Qz, qrec, qmax, m, m_pad, q_splits, idx_prev, out_key, out_idx) \

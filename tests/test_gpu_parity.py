@@ -597,3 +597,27 @@ def test_filter_variants_nonfinite_and_outliers(matrix_pipe, monkeypatch):
             for splits in (1, 3):
                 got = icp_amd.correspondences(a, np.zeros(3), b, search=search, q_splits=splits)
                 assert np.array_equal(got, want), (name, search, splits)
+
+
+def test_debug_switches_come_from_one_list(monkeypatch):
+    """Every debugging / test switch is an entry of ICP_AMD_DEBUG="name=value,..."; the older spelling as a variable of its own
+    (ICP_AMD_<NAME>) is still read, the list wins, and names that merely share a prefix do not match."""
+    P, Q = synth.make_pair(5000, 6000, seed=12)
+    def splits():
+        e = icp_amd.Engine(search="f32")
+        e.set_target(Q)
+        e.set_source(P)
+        geo = e.search_geometry()
+        e.close()
+        return geo["q_splits"]
+    monkeypatch.delenv("ICP_AMD_DEBUG", raising=False)
+    monkeypatch.delenv("ICP_AMD_QSPLITS", raising=False)
+    default = splits()
+    monkeypatch.setenv("ICP_AMD_DEBUG", "grid_cert=0, qsplits=5,mfma_g=2")
+    assert splits() == 5
+    monkeypatch.setenv("ICP_AMD_QSPLITS", "7")
+    assert splits() == 5                                  # the list wins
+    monkeypatch.setenv("ICP_AMD_DEBUG", "qsplitsx=3,xqsplits=4")
+    assert splits() == 7                                  # near-misses in the list are not this switch; the old spelling is
+    monkeypatch.delenv("ICP_AMD_QSPLITS")
+    assert splits() == default
