@@ -191,6 +191,7 @@ struct icp_amd_engine {
     double reject_d2 = std::numeric_limits<double>::infinity();   // f-4: pairs farther apart get weight 0 (inf = reference)
 
     bool have_target = false, have_source = false, cen_ready = false;
+    bool strict = false;        // the reference's reduction order where the cloud is small enough (icp_amd_options::strict_order)
 
 
     // timing of the search launches
@@ -277,6 +278,14 @@ static int plan_search(icp_amd_engine *e);
 static int prepare_grid_source(icp_amd_engine *e);
 
 static const size_t kMaxRows = 0x7FFFFC00u;  // indices are 32-bit; padded sizes must fit too
+static const size_t kStrictMaxSource = 4096, kStrictMaxTarget = (size_t)1 << 20;   // one lane sums these sequentially
+static bool strict_requested(const icp_amd_options &opt)
+{
+    if (opt.strict_order) return true;
+    const char *v = getenv("ICP_AMD_STRICT_ORDER");
+    if (!v) v = getenv("ICP_STRICT_ORDER");   // the name SURVEY.md 7.3 uses
+    return v && atoi(v) != 0;
+}
 
 static bool wants_grid(const icp_amd_engine *e);
 static void choose_geometry(icp_amd_engine *e);
@@ -322,8 +331,14 @@ extern "C" int icp_amd_set_target(icp_amd_engine *e, const double *Q, size_t m)
     const size_t chunks = (m + kChunk - 1) / kChunk;
     double *part = nullptr;
     HIPCHK(dmalloc(&part, chunks * kCenW * sizeof(double)));
-    hipError_t er = colsum_partials(e->stream, e->stage, Soa3{nullptr, nullptr, nullptr}, m, part);
-    if (er == hipSuccess) er = finalize_centroid(e->stream, part, chunks, (double)m, e->qc);
+    e->strict = strict_requested(e->opt) && e->opt.world == 1;
+    hipError_t er;
+    if (e->strict && m <= kStrictMaxTarget) {
+        er = strict_centroid(e->stream, e->stage, Soa3{nullptr, nullptr, nullptr}, m, e->qc);
+    } else {
+        er = colsum_partials(e->stream, e->stage, Soa3{nullptr, nullptr, nullptr}, m, part);
+        if (er == hipSuccess) er = finalize_centroid(e->stream, part, chunks, (double)m, e->qc);
+    }
     if (er == hipSuccess)
         er = aos_to_soa(e->stream, e->stage, m, m_pad, e->qc, std::numeric_limits<double>::infinity(), e->Qz);
     if (er == hipSuccess) er = build_rec(e->stream, e->Qz, m_pad);
@@ -650,8 +665,14 @@ extern "C" int icp_amd_step_search(icp_amd_engine *e)
             RCCHK(bruteforce_target(e));
             choose_geometry(e);
         }
-        const bool fuse_centroid = grid && e->fuse_centroid && e->total_chunks <= kGridFuseCentroidChunks;
-        if (!fuse_centroid) HIPCHK(finalize_centroid(e->stream, e->cen_part, e->total_chunks, (double)e->n_global, e->pc));
+        // strict order: the centroid as one sequential sum over the cloud as it is now, the covariance likewise (below)
+        const bool strict = e->strict && e->n <= kStrictMaxSource && e->reject_d2 == std::numeric_limits<double>::infinity();
+        const bool fuse_centroid = !strict && grid && e->fuse_centroid && e->total_chunks <= kGridFuseCentroidChunks;
+        if (strict) {
+            if (!e->P.rec) RCCHK(sync_soa(e));
+            HIPCHK(strict_centroid(e->stream, nullptr, e->P, e->n, e->pc));
+        } else if (!fuse_centroid)
+            HIPCHK(finalize_centroid(e->stream, e->cen_part, e->total_chunks, (double)e->n_global, e->pc));
         if (e->opt.kernel_timing) {
             if (e->ev_used >= 4096) RCCHK(drain_events(e));
             RCCHK(time_begin(e, &a, &b));
@@ -732,6 +753,7 @@ extern "C" int icp_amd_step_search(icp_amd_engine *e)
         if (!fused.ran)
             HIPCHK(merge_cov(e->stream, e->P, e->n, e->n_pad, e->pc, e->Qz, e->m, splits, e->keys, e->idxs,
                              grid && !e->P.rec ? e->grid_out : nullptr, grid && e->P.rec, e->idx, e->reject_d2, cov_slot));
+        if (strict) HIPCHK(strict_cov(e->stream, e->P, e->n, e->pc, e->Qz, e->m, e->idx, cov_slot, e->chunks_local));
         e->have_prev = true;
     }
     e->updates_since_search = 0;
@@ -1550,6 +1572,9 @@ extern "C" int icp_amd_cross_cov(const double *P, size_t n, const double Pc[3], 
     HIPCHK(part.alloc(chunks * kCovW * sizeof(double)));
     HIPCHK(rec.alloc(kSolveW * sizeof(double)));
     HIPCHK(cov_from_idx(s, dP, n, pc.as<double>(), dQ, m, di.as<uint32_t>(), part.as<double>()));
+    icp_amd_options none{};
+    if (strict_requested(none) && n <= kStrictMaxSource)   // ICP_AMD_STRICT_ORDER=1: the reference's sequential sum
+        HIPCHK(strict_cov(s, dP, n, pc.as<double>(), dQ, m, di.as<uint32_t>(), part.as<double>(), chunks));
     HIPCHK(solve(s, part.as<double>(), chunks, pc.as<double>(), qc.as<double>(), (double)n, rec.as<double>(), nullptr));
     HIPCHK(hipMemcpyAsync(cov, rec.p, 9 * sizeof(double), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
@@ -1568,8 +1593,13 @@ extern "C" int icp_amd_centroid(const double *A, size_t n, double out[3])
     HIPCHK(part.alloc(chunks * kCenW * sizeof(double)));
     HIPCHK(o.alloc(3 * sizeof(double)));
     HIPCHK(hipMemcpyAsync(a.p, A, n * 3 * sizeof(double), hipMemcpyHostToDevice, s));
-    HIPCHK(colsum_partials(s, a.as<double>(), Soa3{nullptr, nullptr, nullptr}, n, part.as<double>()));
-    HIPCHK(finalize_centroid(s, part.as<double>(), chunks, (double)n, o.as<double>()));
+    icp_amd_options none{};
+    if (strict_requested(none) && n <= kStrictMaxTarget) {   // ICP_AMD_STRICT_ORDER=1: the reference's sequential sum
+        HIPCHK(strict_centroid(s, a.as<double>(), Soa3{nullptr, nullptr, nullptr}, n, o.as<double>()));
+    } else {
+        HIPCHK(colsum_partials(s, a.as<double>(), Soa3{nullptr, nullptr, nullptr}, n, part.as<double>()));
+        HIPCHK(finalize_centroid(s, part.as<double>(), chunks, (double)n, o.as<double>()));
+    }
     HIPCHK(hipMemcpyAsync(out, o.p, 3 * sizeof(double), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     return ICP_AMD_OK;

@@ -196,6 +196,16 @@ hipError_t build_source_rec(hipStream_t s, Soa3 P, size_t rows);
 hipError_t source_rec_to_soa(hipStream_t s, Soa3 P, size_t rows);
 hipError_t grid_order(hipStream_t s, Soa3 P, size_t n, uint32_t *order);
 
+// The reference's own reduction order (icp_amd_options::strict_order), one lane per output.  Source of the rows: aos (n x 3
+// row-major) if given, else the records' A half if P.rec is set, else the SoA arrays.
+// out3[k] = (((0 + a[0][k]) + a[1][k]) + ...) / n                                     (src/libalg/mean.cpp:106-131)
+hipError_t strict_centroid(hipStream_t s, const double *aos, Soa3 P, size_t n, double *out3);
+// partial[0][a*3+b] = sum over i, in order, of Qz[idx[i]][a] * (P[i][b] - pc[b])      (src/cpu/icp.cpp:115-129); the same
+// nine slots of the other `chunks - 1` partial records are zeroed, so that the fixed-order sum over all records that
+// solve() runs returns exactly these nine numbers.  Slots 9.. (sum d^2, pairs) of every record are left as they are.
+hipError_t strict_cov(hipStream_t s, Soa3 P, size_t n, const double *pc, Soa3 Qz, size_t m, const uint32_t *idx, double *partial,
+                      size_t chunks);
+
 // Merge the splits (lowest index among equal keys), write idx[n], and reduce q (x) p per 1024-row chunk
 // into partial[chunk][12].
 hipError_t merge_cov(hipStream_t s, Soa3 P, size_t n, size_t n_pad, const double *pc, Soa3 Qz, size_t m,

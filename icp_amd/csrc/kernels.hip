@@ -1220,6 +1220,70 @@ hipError_t cov_from_idx(hipStream_t s, Soa3 P, size_t n, const double *pc, Soa3 
                                                             nullptr, idx, nullptr, nullptr, (size_t)0, INFINITY, partial);
 }
 
+// ---- strict order: the reference's sequential reductions, one lane per output ----
+__global__ __launch_bounds__(64) void strict_centroid_kernel(const double *__restrict__ aos, const double *__restrict__ x,
+                                                             const double *__restrict__ y, const double *__restrict__ z,
+                                                             const double4 *__restrict__ rec, size_t n, double *__restrict__ out3)
+{
+    const int k = threadIdx.x;
+    if (k >= 3) return;
+    double r = 0.0;
+    if (aos) {
+        for (size_t i = 0; i < n; ++i) r += aos[i * 3 + k];
+    } else if (rec) {
+        for (size_t i = 0; i < n; ++i) {
+            const double4 v = rec[i];
+            r += k == 0 ? v.x : (k == 1 ? v.y : v.z);
+        }
+    } else {
+        const double *c = k == 0 ? x : (k == 1 ? y : z);
+        for (size_t i = 0; i < n; ++i) r += c[i];
+    }
+    out3[k] = r / (double)n;
+}
+
+__global__ __launch_bounds__(64) void strict_cov_kernel(const double *__restrict__ px, const double *__restrict__ py,
+                                                        const double *__restrict__ pz, const double4 *__restrict__ prec, size_t n,
+                                                        const double *__restrict__ pc, const double *__restrict__ qx,
+                                                        const double *__restrict__ qy, const double *__restrict__ qz, size_t m,
+                                                        const uint32_t *__restrict__ idx, double *__restrict__ partial, size_t chunks)
+{
+    const int k = threadIdx.x;
+    if (k >= 9) return;
+    const int a = k / 3, b = k % 3;
+    const double cb = pc[b];
+    const double *qa = a == 0 ? qx : (a == 1 ? qy : qz);
+    const double *pb = b == 0 ? px : (b == 1 ? py : pz);
+    double cov = 0.0;
+    for (size_t i = 0; i < n; ++i) {
+        const uint32_t j = idx[i];
+        if (!(j < m)) continue;   // (the reference has a match for every row of a finite cloud)
+        double p;
+        if (prec) {
+            const double4 v = prec[i];
+            p = (b == 0 ? v.x : (b == 1 ? v.y : v.z)) - cb;
+        } else {
+            p = pb[i] - cb;
+        }
+        cov = cov + qa[j] * p;   // tmp = 0 + q_a p_b; tmp *= 1.0; cov += tmp
+    }
+    partial[k] = cov;
+    for (size_t c = 1; c < chunks; ++c) partial[c * kCovW + k] = 0.0;
+}
+
+hipError_t strict_centroid(hipStream_t s, const double *aos, Soa3 P, size_t n, double *out3)
+{
+    if (n == 0) return hipErrorInvalidValue;
+    return launch(strict_centroid_kernel, dim3(1), dim3(64), 0, s, aos, P.x, P.y, P.z, aos ? nullptr : P.rec, n, out3);
+}
+
+hipError_t strict_cov(hipStream_t s, Soa3 P, size_t n, const double *pc, Soa3 Qz, size_t m, const uint32_t *idx, double *partial,
+                      size_t chunks)
+{
+    if (n == 0 || chunks == 0) return hipErrorInvalidValue;
+    return launch(strict_cov_kernel, dim3(1), dim3(64), 0, s, P.x, P.y, P.z, P.rec, n, pc, Qz.x, Qz.y, Qz.z, m, idx, partial, chunks);
+}
+
 hipError_t solve(hipStream_t s, const double *partial, size_t count, const double *pc, const double *qc, double n_global,
                  double *out, double *extra)
 {

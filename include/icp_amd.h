@@ -83,7 +83,14 @@ typedef struct icp_amd_options {
      * Each holds world * chunks_per_rank * width doubles, rank-major; width 12 (cov) / 3 (centroid). */
     double *cov_gather;
     double *cen_gather;
-    int    reserved[8];
+    /* 1 (or ICP_AMD_STRICT_ORDER=1 in the environment): both reductions of an iteration in the reference's own order -- the
+     * centroid as a sequential sum over the rows followed by one division (src/libalg/mean.cpp:106-131), the cross-covariance
+     * as cov += q_a * p_b row by row (src/cpu/icp.cpp:115-129) -- by one lane per output, so that Pc and cov are BIT-identical
+     * to the reference's given the same cloud (the default, fixed-order trees, agrees to ~1e-15).  For clouds of up to 4096
+     * source rows (1 Mi target rows for the target's centroid) on one GPU; larger clouds, sharded runs and the rejection hook
+     * keep the trees.  Indices are identical either way.  SURVEY.md 7.3-3c. */
+    int    strict_order;
+    int    reserved[7];
 } icp_amd_options;
 
 const char *icp_amd_last_error(void);

@@ -559,6 +559,17 @@ def test_cli_on_the_cow_pair_20_iterations(tmp_path):
     assert relerr(np.load(tmp_path / "out.npy"), g["P_out"]) < TOL
     lines = open(tmp_path / "point_cloud_result").read().split("\n")
     assert lines[0] == " dim0: %d dim1: 3 array: " % len(g["P"])
+    # --bench (additive sixth argument): the same stdout line and result file, one JSON line on stderr
+    import json
+    first_out, first_file = r.stdout, open(tmp_path / "point_cloud_result").read()
+    rb = subprocess.run([exe, "P.txt", "Q.txt", str(int(g["iters"])), "-shared-loop", "--bench"], cwd=tmp_path, capture_output=True,
+                        text=True, timeout=120, env=env)
+    assert rb.returncode == 0, rb.stderr
+    assert rb.stdout == first_out and open(tmp_path / "point_cloud_result").read() == first_file
+    d = json.loads([ln for ln in rb.stderr.splitlines() if ln.startswith("{")][-1])
+    assert d["n"] == d["m"] == len(g["P"]) and d["iters"] == int(g["iters"]) and d["gpus"] == 1 and d["cpu_cores"] >= 1
+    assert d["iters_per_sec"] > 0 and d["pairs_per_sec"] > 0 and d["search"]["variant"] == "grid" and d["search"]["launches"] == d["iters"]
+    assert 0 < d["roofline"]["frac"] < 1 and d["roofline"]["bound"] == "hbm"
 
 
 @pytest.mark.gpu
@@ -621,3 +632,39 @@ def test_debug_switches_come_from_one_list(monkeypatch):
     assert splits() == 7                                  # near-misses in the list are not this switch; the old spelling is
     monkeypatch.delenv("ICP_AMD_QSPLITS")
     assert splits() == default
+
+
+@pytest.mark.parametrize("name", ["c1_30pts", "syn256", "syn1k", "cow_tr1"])
+def test_strict_order_reductions_are_bit_identical_to_the_reference(name, monkeypatch):
+    """ICP_AMD_STRICT_ORDER=1 / Engine(strict_order=True) (clouds of up to 4096 rows): the centroid as the
+    reference's sequential sum over the rows followed by one division (src/libalg/mean.cpp:106-131) and the cross-covariance as
+    its row-by-row cov += q_a p_b (src/cpu/icp.cpp:115-129), one lane per output: Qc, Pc and cov are then BIT-identical to the
+    reference's on the reference's own running clouds, where the default trees agree to ~1e-15.  Indices do not change."""
+    g = golden(name)
+    P, Q, Qc = g["P"], g["Q"], g["Qc"]
+    monkeypatch.setenv("ICP_AMD_STRICT_ORDER", "1")
+    assert np.array_equal(icp_amd.centroid(Q), Qc)
+    Qz = Q - Qc
+    for slot, it in enumerate(g["P_in_iters"]):
+        P_in = g["P_in"][slot]
+        assert np.array_equal(icp_amd.centroid(P_in), g["Pc"][it]), (name, it)
+        assert np.array_equal(icp_amd.cross_cov(P_in, g["Pc"][it], Qz, g["idx"][it]), g["cov"][it]), (name, it)
+    monkeypatch.delenv("ICP_AMD_STRICT_ORDER")
+    # the engine: first iteration bit for bit (later ones start from a cloud that went through our SVD instead of LAPACK's)
+    for search in ("auto", "f32"):
+        e = icp_amd.Engine(search=search, strict_order=True)
+        e.set_target(Q)
+        e.set_source(P)
+        assert np.array_equal(e.target_centroid(), Qc)
+        e.iterate(1)
+        last = e.get_last()
+        assert np.array_equal(last["Pc"], g["Pc"][0]) and np.array_equal(last["cov"], g["cov"][0]), (name, search)
+        assert np.array_equal(last["idx"], g["idx"][0])
+        e.iterate(int(g["iters"]) - 1)
+        last = e.get_last()
+        assert np.array_equal(last["idx"], g["idx"][-1])
+        assert relerr(last["R"], g["R"][-1]) < TOL and relerr(e.get_source(), g["P_out"]) < TOL
+        e.close()
+    # and the default order is NOT bit-identical everywhere (else this test would prove nothing) but agrees to 1e-13
+    d = icp_amd.centroid(g["P_in"][0])
+    assert relerr(d, g["Pc"][0]) < 1e-13
