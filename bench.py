@@ -44,7 +44,7 @@ def measured_traffic(kernel, n, m, world):
         rec = json.load(open(os.path.join(ROOT, "icp_amd", "measured_traffic.json"))).get(kernel)
     except (OSError, ValueError):
         return None, "no measured_traffic.json", None
-    if not rec or (rec["n"], rec["m"], rec["n_gpus"]) != (n, m, world):
+    if not rec or (rec["n"], rec["m"] if m is not None else None, rec["n_gpus"]) != (n, m, world):
         return None, "no PMC pass on this workload", None
     src = rec.get("kernel_source")
     try:
@@ -92,6 +92,29 @@ def roofline(variant, n_local, M, avg_ms, launches):
             "note": ("fp32 vector peak 157.3 TFLOP/s" if f32 else
                      "un-fused fp64 VALU peak 39.3 TFLOP/s = one flop per op (FMA-counted datasheet peak: 78.6); the FMA "
                      "variant issues 7.08 instructions for the 8 algorithmic flops, so its frac can pass 1")}
+
+
+# what the box's memory system delivers for plain streams at the grid iteration's sizes (tools/ubench_stream.hip at 1M rows,
+# profiles/r3_ubench_stream.txt): a copy (32 B in, 32 B out per row) and two read streams + one write stream
+MEASURED_COPY_TBPS, MEASURED_2R1W_TBPS = 5.69, 6.83
+GRID_SEARCH_BYTES_PER_ROW = 100      # settled search + covariance: record halves A, B in (64), B out (32), index out (4)
+GRID_ITERATION_BYTES_PER_ROW = 164   # + transform apply: half A in, half A out (64); solve and centroid move nothing per row
+
+
+def grid_roofline(n_local, kernel_ms, step_s, world):
+    ach = GRID_SEARCH_BYTES_PER_ROW * n_local / (kernel_ms * 1e-3) if kernel_ms > 0 else 0.0
+    it = GRID_ITERATION_BYTES_PER_ROW * n_local / step_s if step_s > 0 else 0.0
+    tb, src, blob = measured_traffic("search_grid_settled_kernel", n_local, None, world)
+    return {"bound": "hbm", "kernel": "search_grid_settled_kernel (search + covariance sums in one launch)", "achieved": ach / 1e9,
+            "peak": 8000.0, "unit": "GB/s", "frac": ach / 8e12, "algorithmic_bytes_per_row": GRID_SEARCH_BYTES_PER_ROW,
+            "avg_launch_ms": kernel_ms, "traffic": tb, "traffic_source_commit": blob, "traffic_note": src,
+            "frac_of_measured_2r1w_rate": ach / (MEASURED_2R1W_TBPS * 1e12),
+            "iteration_bytes_per_row": GRID_ITERATION_BYTES_PER_ROW, "iteration_frac": it / 8e12,
+            "iteration_frac_of_measured_copy_rate": it / (MEASURED_COPY_TBPS * 1e12),
+            "measured_stream_rates_tbps": {"copy": MEASURED_COPY_TBPS, "two_reads_one_write": MEASURED_2R1W_TBPS,
+                                           "source": "tools/ubench_stream.hip at 1M rows, profiles/r3_ubench_stream.txt"},
+            "note": "`iteration_*`: the three launches of a settled iteration that move rows (search + covariance 100 B per row, "
+                    "apply 64) against the whole step time, which also holds the solve (10 us) and the centroid launch (4 us)"}
 
 
 def fp64_variants(P, Q, device, steps=3):
@@ -534,16 +557,10 @@ def main():
                 "speedup_vs_brute_force": (dt / args.steps) / (g_dt / g_steps), "search_kernel_avg_ms": g_ms,
                 "search": g_geo, "stats": g_stats, "first_step_ms": gr["first_ms"],
                 "ms_per_step_by_10": gr["ms_per_step_by_10"],
-                # HBM roofline of the settled grid search (hipEvent average of search_grid_kernel over the timed launches):
-                # 96 algorithmic bytes per source row -- its 64-byte record in, the 32-byte result half out
-                "roofline": {"bound": "hbm", "kernel": "search_grid_kernel", "achieved": 96.0 * gr["n_local"] / (g_ms * 1e-3) / 1e9
-                             if g_ms > 0 else 0.0, "peak": 8000.0, "unit": "GB/s",
-                             "frac": 96.0 * gr["n_local"] / (g_ms * 1e-3) / 8e12 if g_ms > 0 else 0.0,
-                             "algorithmic_bytes_per_row": 96, "avg_launch_ms": g_ms, "traffic": None,
-                             "iteration_bytes_per_row": 248,
-                             "iteration_frac": 248.0 * gr["n_local"] / (g_dt / g_steps) / 8e12,
-                             "note": "`iteration_*`: all five kernels of a settled iteration (search 96 B per row, covariance "
-                                     "68, apply 84) against the whole step time"},
+                # HBM roofline of the settled grid search (hipEvent average over the timed launches).  Since round 3 that launch is
+                # search_grid_settled_kernel, which searches AND forms the covariance sums: 100 algorithmic bytes per source row --
+                # the row's two 32-byte record halves in, the match half out, 4 bytes of index out
+                "roofline": grid_roofline(gr["n_local"], g_ms, g_dt / g_steps, world),
                 "first_steps": {"ms_per_step": early["dt"] / g_steps * 1e3, "iters_per_sec": g_steps / early["dt"], "steps": g_steps,
                                 "warmup_steps": max(args.warmup, 3), "ms_per_step_by_10": early["ms_per_step_by_10"],
                                 "search_kernel_avg_ms": early["avg_ms"]},

@@ -72,9 +72,28 @@ def main_batch(argv):
     print(json.dumps(rec["batch_icp_kernel"], indent=2))
 
 
+def main_grid(argv):
+    """--grid fetch.txt write.txt n: the settled grid search (icp_amd/csrc/grid.hip: search_grid_settled_kernel)"""
+    fetch_txt, write_txt, n = argv[0], argv[1], int(argv[2])
+    src = os.path.join("icp_amd", "csrc", "grid.hip")
+    fetch_kb, nd = per_dispatch_any(fetch_txt, "icpk::search_grid_settled_kernel", "FETCH_SIZE")
+    write_kb, _ = per_dispatch_any(write_txt, "icpk::search_grid_settled_kernel", "WRITE_SIZE")
+    path = os.path.join(ROOT, "icp_amd", "measured_traffic.json")
+    rec = json.load(open(path))
+    rec["search_grid_settled_kernel"] = {
+        "n": n, "m": n, "n_gpus": 1, "fetch_size_kb": fetch_kb, "write_size_kb": write_kb,
+        "traffic_bytes": int(round((2.0 * fetch_kb + write_kb) * 1024)),
+        "source": "%s, %s (%d dispatches)" % (fetch_txt, write_txt, nd),
+        "kernel_source": src, "kernel_source_blob": blob_hash(os.path.join(ROOT, src))}
+    json.dump(rec, open(path, "w"), indent=2)
+    print(json.dumps(rec["search_grid_settled_kernel"], indent=2))
+
+
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "--batch":
         return main_batch(sys.argv[2:])
+    if len(sys.argv) > 1 and sys.argv[1] == "--grid":
+        return main_grid(sys.argv[2:])
     fetch_txt, write_txt = sys.argv[1], sys.argv[2]
     n, m, g = (int(x) for x in sys.argv[3:6]) if len(sys.argv) >= 6 else (1000000, 1000000, 1)
     fetch_kb, nd = per_dispatch(fetch_txt, "icpk::search_mfma16_kernel", "FETCH_SIZE")
