@@ -667,7 +667,7 @@ extern "C" int icp_amd_step_search(icp_amd_engine *e)
         }
         // strict order: the centroid as one sequential sum over the cloud as it is now, the covariance likewise (below)
         const bool strict = e->strict && e->n <= kStrictMaxSource && e->reject_d2 == std::numeric_limits<double>::infinity();
-        const bool fuse_centroid = !strict && grid && e->fuse_centroid && e->total_chunks <= kGridFuseCentroidChunks;
+        const bool fuse_centroid = !strict && grid && e->fuse_centroid;   // search_grid() finishes the centroid: inside its kernel, or by a launch of its own
         if (strict) {
             if (!e->P.rec) RCCHK(sync_soa(e));
             HIPCHK(strict_centroid(e->stream, nullptr, e->P, e->n, e->pc));
@@ -765,9 +765,9 @@ extern "C" int icp_amd_step_update(icp_amd_engine *e)
     if (!e || !e->have_source) return fail(ICP_AMD_ESTATE, "icp_amd_step_update: no source cloud");
     HIPCHK(set_device(e->opt.device));
     const bool rejecting = e->reject_d2 < std::numeric_limits<double>::infinity();
+    double *cen_slot = e->cen_part + (size_t)e->opt.rank * e->cpr * kCenW;
     HIPCHK(solve(e->stream, e->cov_part, e->total_chunks, e->pc, e->qc, rejecting ? -1.0 : (double)e->n_global, e->rec,
                  e->rec + kSolveW));
-    double *cen_slot = e->cen_part + (size_t)e->opt.rank * e->cpr * kCenW;
     HIPCHK(apply(e->stream, e->P, e->n, e->rec, cen_slot));
     if (e->P.rec && e->n) e->soa_stale = true;   // only the records' A half was updated
     ++e->updates_since_search;

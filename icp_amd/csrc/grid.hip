@@ -345,13 +345,14 @@ __global__ __launch_bounds__(kWG) void grid_occupied_kernel(const uint32_t *__re
 // workgroup for itself -- the fixed-order sum of the chunk partials that finalize_centroid_kernel would run as a launch of its
 // own (3.7 us of a 30 us iteration); identical code on identical inputs, so every workgroup holds the same bits, and
 // workgroup 0 publishes them for the kernels that follow.  Every thread of the workgroup must call it (barriers).
+template <int BATCH = kSumGroup>   // loads in flight per thread while the partials are summed (registers)
 __device__ __forceinline__ void grid_launch_centroid(double *__restrict__ pc_io, const double *__restrict__ cen_part, unsigned cen_chunks,
                                                      double cen_denom, double pc[3])
 {
     if (cen_part) {
         __shared__ double s_stage[kWG];
         __shared__ double s_pc[3];
-        const double acc = ordered_sum<kCenW, kWG>(cen_part, cen_chunks, s_stage);
+        const double acc = ordered_sum<kCenW, kWG, BATCH>(cen_part, cen_chunks, s_stage);
         if (threadIdx.x < 3) {
             s_pc[threadIdx.x] = acc / cen_denom;
             if (blockIdx.x == 0) pc_io[threadIdx.x] = acc / cen_denom;
@@ -744,6 +745,23 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
     if (need) grid_row_walk<ROWS, FLIGHT>(ctx, row);
 }
 
+// One row's contribution to the chunk's covariance sums, exactly as cov_rec_kernel (kernels.hip) forms it; stores the row's index.
+__device__ __forceinline__ void cov_row_sums(unsigned m, double reject_d2, double p0, double p1, double p2, double q0, double q1, double q2,
+                                             uint32_t j, uint32_t *__restrict__ idx_slot, double (&acc)[kCovW])
+{
+    *idx_slot = j;
+    if (j < m) {
+        const double d = d2_exact(p0, p1, p2, q0, q1, q2);
+        if (d <= reject_d2) {
+            acc[0] += q0 * p0; acc[1] += q0 * p1; acc[2] += q0 * p2;
+            acc[3] += q1 * p0; acc[4] += q1 * p1; acc[5] += q1 * p2;
+            acc[6] += q2 * p0; acc[7] += q2 * p1; acc[8] += q2 * p2;
+            acc[9] += d;
+            acc[10] += 1.0;
+        }
+    }
+}
+
 // The settled registration: (nearly) every row keeps its match by certificate and the search is a stream over the row
 // records -- from whose registers the iteration's covariance can be had as well.  One workgroup per 1024-row chunk in
 // storage order, four rows per lane with all eight record loads in flight, exactly the shape of cov_rec_kernel
@@ -754,7 +772,7 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
 // and the lanes that own those rows read the results back before the sums are formed.  The host launches it when the previous
 // search reported a settled registration (a mapped word, possibly a launch old): the choice never changes a result.
 template <int ROWS, int FLIGHT>
-__global__ __launch_bounds__(kWG) void search_grid_settled_kernel(GridCtx ctx_in, double *__restrict__ pc_io, size_t n,
+__global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(4, 4))) void search_grid_settled_kernel(GridCtx ctx_in, double *__restrict__ pc_io, size_t n,
                                                                   const double *__restrict__ cen_part, unsigned cen_chunks, double cen_denom,
                                                                   double order_switch, uint32_t *__restrict__ settled_hint,
                                                                   uint32_t *__restrict__ idx_out, double reject_d2,
@@ -764,14 +782,12 @@ __global__ __launch_bounds__(kWG) void search_grid_settled_kernel(GridCtx ctx_in
     __shared__ uint32_t s_walk[kChunk];
     __shared__ uint32_t s_walkers;
     GridCtx ctx = ctx_in;
-    grid_launch_centroid(pc_io, cen_part, cen_chunks, cen_denom, ctx.pc);
-    if (settled_hint && blockIdx.x == 0 && threadIdx.x == 0)
-        *settled_hint = grid_settled(ctx.g, ctx.mot, ctx.pc, order_switch) ? 1u : 0u;
-    if (threadIdx.x == 0) s_walkers = 0;
     double4 *__restrict__ prec = ctx.prec;
     const size_t stride = ctx.prec_stride;
     const size_t base = (size_t)blockIdx.x * kChunk + threadIdx.x;
     constexpr int PER = kChunk / kWG;
+    // The rows first: their eight loads are on their way while the workgroup finishes the centroid (a sum over partials that
+    // sit in the L2 and two barriers -- 2 us that used to precede the first row load, or a launch of its own before this one).
     double4 v0[PER], v1[PER];
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
@@ -779,19 +795,27 @@ __global__ __launch_bounds__(kWG) void search_grid_settled_kernel(GridCtx ctx_in
         v0[k] = prec[ic];
         v1[k] = prec[stride + ic];
     }
+    if (threadIdx.x == 0) s_walkers = 0;
+    grid_launch_centroid<16>(pc_io, cen_part, cen_chunks, cen_denom, ctx.pc);
+    if (settled_hint && blockIdx.x == 0 && threadIdx.x == 0)
+        *settled_hint = grid_settled(ctx.g, ctx.mot, ctx.pc, order_switch) ? 1u : 0u;
     __syncthreads();
-    // what the sums need of a row: p = A - pc as cov_rec_kernel forms it, q = the matched target, j = its index
-    double p[PER][3], q[PER][3];
-    uint32_t jm[PER];
+    // cov_rec_kernel's sums, in its order, formed as the rows are decided: p = A - pc as cov_rec_kernel forms it, q = the
+    // matched target, j = its index (certificate held: the seed; no finite coordinates: none).  Should a row of the workgroup
+    // have to walk, these sums are dropped and formed again from the chunk as it is after the walk (below) -- keeping the
+    // rows' operands in registers instead cost a wave per SIMD (148 registers against 128: 977 workgroups at 1M rows are then
+    // two rounds over the 256 CUs instead of one).
+    double acc[kCovW];
+#pragma unroll
+    for (int k = 0; k < kCovW; ++k) acc[k] = 0.0;
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
         GridRow row;
         row.i = base + (size_t)k * kWG;
-        const bool need = row.i < n && grid_row_setup(ctx, row, v0[k], v1[k]);
-        if (need) s_walk[atomicAdd(&s_walkers, 1u)] = (uint32_t)row.i;
-        p[k][0] = row.ax; p[k][1] = row.ay; p[k][2] = row.az;
-        q[k][0] = row.sqx; q[k][1] = row.sqy; q[k][2] = row.sqz;
-        jm[k] = row.bj;   // certificate held: the seed; no finite coordinates: none
+        if (row.i < n) {
+            if (grid_row_setup(ctx, row, v0[k], v1[k])) s_walk[atomicAdd(&s_walkers, 1u)] = (uint32_t)row.i;
+            cov_row_sums(ctx.m, reject_d2, row.ax, row.ay, row.az, row.sqx, row.sqy, row.sqz, row.bj, idx_out + row.i, acc);
+        }
     }
     __syncthreads();
     const uint32_t walkers = s_walkers;   // the same in every lane
@@ -806,38 +830,18 @@ __global__ __launch_bounds__(kWG) void search_grid_settled_kernel(GridCtx ctx_in
         __syncthreads();   // ... before the lanes that own those rows read them (past their L1, where the old line may sit).
         // Nothing of the rows was kept in registers across the walk: a workgroup that had to walk reads its chunk again.
 #pragma unroll
+        for (int k = 0; k < kCovW; ++k) acc[k] = 0.0;
+#pragma unroll
         for (int k = 0; k < PER; ++k) {
-            const size_t i = base + (size_t)k * kWG, ic = i < n ? i : n - 1;
-            const double4 a = prec[ic];
-            const double *b = (const double *)&prec[stride + ic];
-            p[k][0] = a.x - ctx.pc[0]; p[k][1] = a.y - ctx.pc[1]; p[k][2] = a.z - ctx.pc[2];
-            q[k][0] = __hip_atomic_load(b + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            q[k][1] = __hip_atomic_load(b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            q[k][2] = __hip_atomic_load(b + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            jm[k] = (uint32_t)__hip_atomic_load((const unsigned long long *)(b + 3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-    // cov_rec_kernel's sums, in its order
-    double acc[kCovW];
-#pragma unroll
-    for (int k = 0; k < kCovW; ++k) acc[k] = 0.0;
-#pragma unroll
-    for (int k = 0; k < PER; ++k) {
-        const size_t i = base + (size_t)k * kWG;
-        if (i < n) {
-            const uint32_t j = jm[k];
-            idx_out[i] = j;
-            if (j < ctx.m) {
-                const double p0 = p[k][0], p1 = p[k][1], p2 = p[k][2];
-                const double q0 = q[k][0], q1 = q[k][1], q2 = q[k][2];
-                const double d = d2_exact(p0, p1, p2, q0, q1, q2);
-                if (d <= reject_d2) {
-                    acc[0] += q0 * p0; acc[1] += q0 * p1; acc[2] += q0 * p2;
-                    acc[3] += q1 * p0; acc[4] += q1 * p1; acc[5] += q1 * p2;
-                    acc[6] += q2 * p0; acc[7] += q2 * p1; acc[8] += q2 * p2;
-                    acc[9] += d;
-                    acc[10] += 1.0;
-                }
+            const size_t i = base + (size_t)k * kWG;
+            if (i < n) {
+                const double4 a = prec[i];
+                const double *b = (const double *)&prec[stride + i];
+                const double q0 = __hip_atomic_load(b + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const double q1 = __hip_atomic_load(b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const double q2 = __hip_atomic_load(b + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t j = (uint32_t)__hip_atomic_load((const unsigned long long *)(b + 3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                cov_row_sums(ctx.m, reject_d2, a.x - ctx.pc[0], a.y - ctx.pc[1], a.z - ctx.pc[2], q0, q1, q2, j, idx_out + i, acc);
             }
         }
     }
@@ -1145,7 +1149,17 @@ hipError_t search_grid(hipStream_t s, Soa3 P, size_t n, double *pc, const Grid &
     // Rows per group x loads in flight: 4 x 4.  Measured against 4 x 8, 8 x 4 and 8 x 8 (profiles/r2_v2_grid_shape_ab.txt): eight
     // loads in flight are 9-12 % slower everywhere (registers: 4 or 3 waves per SIMD instead of 5, and more masked slots),
     // eight rows per group are equal on volumes and 10 % faster only on the first searches of a 1M-point sheet.
-    if (fused && fused->idx_out && fused->partial && all && all->fuse_cov && hint && all->host_mem[1] == 1u && P.rec && idx_prev && motion) {
+    const bool settled_launch = fused && fused->idx_out && fused->partial && all && all->fuse_cov && hint && all->host_mem[1] == 1u &&
+                                P.rec && idx_prev && motion;
+    // cen_part: the launch is asked to finish the centroid itself.  The settled kernel does that behind its row loads for any
+    // cloud whose partials one pass of the sum covers; search_grid_kernel, whose workgroups are a quarter of the rows and
+    // four times as many, only for small clouds -- otherwise the sum runs as the launch of its own that it would have been.
+    if (cen_part && cen_chunks > (settled_launch ? kGridFuseCentroidChunksSettled : kGridFuseCentroidChunks)) {
+        hipError_t ec = finalize_centroid(s, cen_part, cen_chunks, cen_denom, pc);
+        if (ec != hipSuccess) return ec;
+        cen_part = nullptr;
+    }
+    if (settled_launch) {
         GridCtx c{};
         c.px = P.x; c.py = P.y; c.pz = P.z; c.g = g.d; c.start = g.start; c.rec = g.rec; c.qx = Qz.x; c.qy = Qz.y; c.qz = Qz.z;
         c.qrec4 = Qz.rec; c.m = (unsigned)m; c.idx_prev = idx_prev; c.prec = P.rec; c.prec_stride = P.rec_stride; c.row_cap = row_cap;

@@ -175,8 +175,12 @@ void grid_scratch_free(GridScratch *sc);
 // cell (grid.hip); nullptr = every row is searched.
 // cen_part != nullptr: pc is an OUTPUT -- the launch finishes the centroid itself from cen_chunks chunk partials
 // (pc = fixed-order sum / cen_denom, the result of finalize_centroid) and workgroup 0 stores it in pc for the kernels that
-// follow; meant for clouds of up to kGridFuseCentroidChunks chunks, where that saves a launch for a 3 KB re-read per workgroup.
+// follow.  search_grid() decides: the search kernel proper does so for clouds of up to kGridFuseCentroidChunks chunks (a launch
+// saved for a 3 KB re-read per workgroup), the settled kernel -- whose row loads are in flight meanwhile -- up to
+// kGridFuseCentroidChunksSettled (one pass of the fixed-order sum: 32 * (256 / 3) chunks); beyond that search_grid() runs
+// finalize_centroid as a launch of its own first.
 constexpr size_t kGridFuseCentroidChunks = 128;
+constexpr size_t kGridFuseCentroidChunksSettled = 32 * (kWG / kCenW);
 // fused (optional): the caller offers the outputs of the merge that would follow (merge_cov with result_in_rec): with source
 // records, certificates in play and a registration that the previous search found settled, one launch then does both --
 // fused->ran says whether it did (the caller then skips merge_cov).

@@ -492,40 +492,86 @@ __global__ __launch_bounds__(kWG) void cov_rec_kernel(const double4 *__restrict_
 // (reference src/libgpualg/svd.cu:19-115) / LAPACK dgesvd_ (src/libalg/svd.cpp:36-73).  Only R = U V^T is
 // consumed by the hot path; it is the orthogonal polar factor of A and does not depend on factor signs.
 // Directions of singular values at roundoff level (<= 1e-13 S[0]) are completed so that det(U) = det(V).
-__device__ void svd3(const double *A, double *U, double *S, double *VT)
+//
+// One lane runs this while its launch waits, and a settled grid iteration is three such waits long, so the length of the
+// DEPENDENT chain of a rotation is what counts (measured: 10 us of a 24 us iteration on a 2 903-point cloud).  A rotation
+// therefore takes its reciprocal and its two inverse square roots from the hardware's seed instructions (v_rcp_f64 /
+// v_rsq_f64: 2^-23 relative by their specification) plus two Newton steps each -- about 1 ulp, 35 dependent instructions a
+// rotation where the correctly rounded divisions and roots of the textbook formulas need 87 -- and the convergence test
+// compares squares.  An error of an ulp in c, s or t only changes how completely this rotation annihilates its off-diagonal
+// element (the next sweep sees the rest); what the result's accuracy rests on -- the test itself, the final column norms and
+// the normalisation of U -- is computed with correctly rounded operations.  The matrix is scaled by a power of two to a
+// largest element in [1/2, 1) first (exact), so that no square under- or overflows for any input scale.
+__device__ __forceinline__ double rsqrt_2nr(double x)   // x in [1/4, 4]
+{
+    double y = __builtin_amdgcn_rsq(x);
+    double e = __builtin_fma(-(x * y), y, 1.0);
+    y = __builtin_fma(0.5 * y, e, y);
+    e = __builtin_fma(-(x * y), y, 1.0);
+    return __builtin_fma(0.5 * y, e, y);
+}
+__device__ __forceinline__ double rcp_2nr(double x)   // likewise
+{
+    double y = __builtin_amdgcn_rcp(x);
+    double e = __builtin_fma(-x, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    e = __builtin_fma(-x, y, 1.0);
+    return __builtin_fma(y, e, y);
+}
+
+// One rotation of columns P and Q of a (and of v): false = they are orthogonal already.
+constexpr double kJacobiOff = 4.5e-16 * 4.5e-16;   // converged: |a_p . a_q| <= 4.5e-16 |a_p| |a_q|, compared as squares
+template <int P, int Q>
+__device__ __forceinline__ bool jacobi_pair(double (&a)[9], double (&v)[9])
+{
+    const double alpha = (a[P] * a[P] + a[3 + P] * a[3 + P]) + a[6 + P] * a[6 + P];
+    const double beta = (a[Q] * a[Q] + a[3 + Q] * a[3 + Q]) + a[6 + Q] * a[6 + Q];
+    const double gamma = (a[P] * a[Q] + a[3 + P] * a[3 + Q]) + a[6 + P] * a[6 + Q];
+    if (gamma == 0.0 || gamma * gamma <= kJacobiOff * (alpha * beta)) return false;
+    // t = tan of the rotation angle, the smaller root: sign(zeta) / (|zeta| + sqrt(1 + zeta^2)) with
+    // zeta = (beta - alpha) / (2 gamma), written without the division by gamma: t = sign(d) g / (|d| + sqrt(d^2 + g^2)),
+    // d = beta - alpha, g = 2 gamma -- a ratio, so d and g are first scaled by a power of two to max(|d|, |g|) in [1/2, 1):
+    // the sum of squares is then in [1/4, 2) whatever the norms of the two columns are.
+    const double d0 = beta - alpha, g0 = gamma + gamma;
+    const int e2 = __builtin_amdgcn_frexp_exp(__builtin_fmax(__builtin_fabs(d0), __builtin_fabs(g0)));
+    const double d = __builtin_amdgcn_ldexp(d0, -e2), g2 = __builtin_amdgcn_ldexp(g0, -e2);
+    const double x = d * d + g2 * g2;
+    const double h = x * rsqrt_2nr(x);
+    const double tt = (d >= 0.0 ? g2 : -g2) * rcp_2nr(__builtin_fabs(d) + h);
+    const double c = rsqrt_2nr(1.0 + tt * tt);
+    const double s = c * tt;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        double x0 = a[i * 3 + P], y0 = a[i * 3 + Q];
+        a[i * 3 + P] = c * x0 - s * y0;
+        a[i * 3 + Q] = s * x0 + c * y0;
+        x0 = v[i * 3 + P];
+        y0 = v[i * 3 + Q];
+        v[i * 3 + P] = c * x0 - s * y0;
+        v[i * 3 + Q] = s * x0 + c * y0;
+    }
+    return true;
+}
+
+__device__ __forceinline__ void svd3(const double *A, double *U, double *S, double *VT)
 {
     double a[9], v[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-    for (int k = 0; k < 9; ++k) a[k] = A[k];
+    double amax = 0.0;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) amax = __builtin_fmax(amax, __builtin_fabs(A[k]));   // (NaN elements are skipped here and poison the sweeps)
+    int ex = 0;
+    if (amax > 0.0 && amax < INFINITY) ex = __builtin_amdgcn_frexp_exp(amax);   // amax = f * 2^ex, f in [1/2, 1)
+#pragma unroll
+    for (int k = 0; k < 9; ++k) a[k] = __builtin_amdgcn_ldexp(A[k], -ex);
     for (int sweep = 0; sweep < 30; ++sweep) {
-        bool rotated = false;
-        for (int k = 0; k < 3; ++k) {
-            const int p = (k == 2) ? 1 : 0, q = (k == 0) ? 1 : 2;
-            double alpha = 0, beta = 0, gamma = 0;
-            for (int i = 0; i < 3; ++i) {
-                alpha += a[i * 3 + p] * a[i * 3 + p];
-                beta += a[i * 3 + q] * a[i * 3 + q];
-                gamma += a[i * 3 + p] * a[i * 3 + q];
-            }
-            if (gamma == 0.0 || fabs(gamma) <= 4.5e-16 * sqrt(alpha * beta)) continue;
-            rotated = true;
-            const double zeta = (beta - alpha) / (2.0 * gamma);
-            const double tt = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-            const double c = 1.0 / sqrt(1.0 + tt * tt), s = c * tt;
-            for (int i = 0; i < 3; ++i) {
-                double x = a[i * 3 + p], y = a[i * 3 + q];
-                a[i * 3 + p] = c * x - s * y;
-                a[i * 3 + q] = s * x + c * y;
-                x = v[i * 3 + p];
-                y = v[i * 3 + q];
-                v[i * 3 + p] = c * x - s * y;
-                v[i * 3 + q] = s * x + c * y;
-            }
-        }
-        if (!rotated) break;
+        const bool r01 = jacobi_pair<0, 1>(a, v);
+        const bool r02 = jacobi_pair<0, 2>(a, v);
+        const bool r12 = jacobi_pair<1, 2>(a, v);
+        if (!(r01 || r02 || r12)) break;
     }
     double sg[3];
     int ord[3] = {0, 1, 2};
-    for (int j = 0; j < 3; ++j) sg[j] = sqrt(a[j] * a[j] + a[3 + j] * a[3 + j] + a[6 + j] * a[6 + j]);
+    for (int j = 0; j < 3; ++j) sg[j] = sqrt(a[j] * a[j] + a[3 + j] * a[3 + j] + a[6 + j] * a[6 + j]);   // of the scaled matrix
     for (int i = 0; i < 2; ++i)
         for (int j = 0; j < 2 - i; ++j)
             if (sg[ord[j]] < sg[ord[j + 1]]) {
@@ -538,7 +584,7 @@ __device__ void svd3(const double *A, double *U, double *S, double *VT)
     int rank = 0;
     for (int j = 0; j < 3; ++j) {
         const int c = ord[j];
-        S[j] = sg[c];
+        S[j] = __builtin_amdgcn_ldexp(sg[c], ex);
         for (int i = 0; i < 3; ++i) vv[i * 3 + j] = v[i * 3 + c];
         const bool ok = sg[c] > 0.0 && sg[c] > tol && rank == j;
         for (int i = 0; i < 3; ++i) u[i * 3 + j] = ok ? a[i * 3 + c] / sg[c] : 0.0;
@@ -575,7 +621,34 @@ __device__ void svd3(const double *A, double *U, double *S, double *VT)
         }
 }
 
-__device__ void solve_record(const double *tot, const double *pc, const double *qc, double n_global, double *out);
+__device__ __forceinline__ void solve_record(const double *tot, const double *pc, const double *qc, double n_global, double *out);
+
+// One lane, after solve_record: pairs used; how far this iteration's motion is from the identity (convergence test of the
+// caller); how far R is from orthogonal.  out = the solve record, pc = the centroid the motion was solved about.
+__device__ __forceinline__ void solve_extra(const double *out, const double *pc, double pairs, double *extra)
+{
+    double dr = 0.0, dt = 0.0;
+    for (int k = 0; k < 9; ++k) dr = fmax(dr, fabs(out[12 + k] - ((k % 4 == 0) ? 1.0 : 0.0)));
+    // the motion of the cloud is x -> R x + t; about its centroid Pc the translation part is R Pc + t - Pc
+    for (int j = 0; j < 3; ++j) {
+        const double moved = ((out[12 + j * 3] * pc[0] + out[12 + j * 3 + 1] * pc[1]) + out[12 + j * 3 + 2] * pc[2]) + out[21 + j];
+        dt = fmax(dt, fabs(moved - pc[j]));
+    }
+    extra[0] = pairs;
+    extra[1] = dr;
+    extra[2] = dt;
+    // |R^T R - I|_F: how far R is from orthogonal (a few ulp; NaN for a NaN covariance) -- the grid search's motion
+    // certificate inverts R by its transpose and asks for < 2^-42
+    double defect = 0.0;
+    for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b) {
+            double g = 0.0;
+            for (int k = 0; k < 3; ++k) g += out[12 + k * 3 + a] * out[12 + k * 3 + b];
+            g -= (a == b) ? 1.0 : 0.0;
+            defect += g * g;
+        }
+    extra[3] = sqrt(defect);
+}
 
 // One workgroup of kSolveWG threads: the fixed-order sum of all chunk partials (one pass of ordered_sum up to
 // 32 * (kSolveWG / kCovW) chunks = 2.7M rows: a single memory latency), then one lane solves.
@@ -592,33 +665,11 @@ __global__ __launch_bounds__(kSolveWG) void solve_kernel(const double *__restric
     if (threadIdx.x != 0) return;
     // n_global <= 0: the rms is taken over the pairs that entered the sums (distance rejection active)
     solve_record(tot, pc, qc, n_global > 0.0 ? n_global : (tot[10] > 0.0 ? tot[10] : 1.0), out);
-    if (extra) {   // pairs used; how far this iteration's motion is from the identity (convergence test of the caller)
-        double dr = 0.0, dt = 0.0;
-        for (int k = 0; k < 9; ++k) dr = fmax(dr, fabs(out[12 + k] - ((k % 4 == 0) ? 1.0 : 0.0)));
-        // the motion of the cloud is x -> R x + t; about its centroid Pc the translation part is R Pc + t - Pc
-        for (int j = 0; j < 3; ++j) {
-            const double moved = ((out[12 + j * 3] * pc[0] + out[12 + j * 3 + 1] * pc[1]) + out[12 + j * 3 + 2] * pc[2]) + out[21 + j];
-            dt = fmax(dt, fabs(moved - pc[j]));
-        }
-        extra[0] = tot[10];
-        extra[1] = dr;
-        extra[2] = dt;
-        // |R^T R - I|_F: how far R is from orthogonal (a few ulp; NaN for a NaN covariance) -- the grid search's motion
-        // certificate inverts R by its transpose and asks for < 2^-42
-        double defect = 0.0;
-        for (int a = 0; a < 3; ++a)
-            for (int b = 0; b < 3; ++b) {
-                double g = 0.0;
-                for (int k = 0; k < 3; ++k) g += out[12 + k * 3 + a] * out[12 + k * 3 + b];
-                g -= (a == b) ? 1.0 : 0.0;
-                defect += g * g;
-            }
-        extra[3] = sqrt(defect);
-    }
+    if (extra) solve_extra(out, pc, tot[10], extra);
 }
 
 // One lane: cov -> SVD -> R, t; writes the 28-double record (layout in kernels.h).
-__device__ void solve_record(const double *tot, const double *pc, const double *qc, double n_global, double *out)
+__device__ __forceinline__ void solve_record(const double *tot, const double *pc, const double *qc, double n_global, double *out)
 {
     double cov[9], U[9], S[3], VT[9], R[9], t[3];
     for (int k = 0; k < 9; ++k) cov[k] = tot[k];
@@ -657,10 +708,6 @@ __global__ __launch_bounds__(kWG) void apply_kernel(double *__restrict__ px, dou
                                                     double *__restrict__ cen_partial)
 {
     __shared__ double smem[4 * 3];
-    const double *R = rec + 12, *t = rec + 21;
-    const double r00 = R[0], r01 = R[1], r02 = R[2], r10 = R[3], r11 = R[4], r12 = R[5], r20 = R[6], r21 = R[7], r22 = R[8];
-    const double t0 = t[0], t1 = t[1], t2 = t[2];
-    double acc[3] = {0.0, 0.0, 0.0};
     const size_t base = (size_t)blockIdx.x * kChunk + threadIdx.x;
     // every load of the workgroup's four row groups goes out before the first dependent use (HBM bound: bytes in flight)
     double lx[kChunk / kWG], ly[kChunk / kWG], lz[kChunk / kWG], lw[kChunk / kWG];
@@ -678,6 +725,10 @@ __global__ __launch_bounds__(kWG) void apply_kernel(double *__restrict__ px, dou
             lw[k] = 0.0;
         }
     }
+    const double *R = rec + 12, *t = rec + 21;
+    const double r00 = R[0], r01 = R[1], r02 = R[2], r10 = R[3], r11 = R[4], r12 = R[5], r20 = R[6], r21 = R[7], r22 = R[8];
+    const double t0 = t[0], t1 = t[1], t2 = t[2];
+    double acc[3] = {0.0, 0.0, 0.0};
 #pragma unroll
     for (int k = 0; k < kChunk / kWG; ++k) {
         const size_t i = base + (size_t)k * kWG;
@@ -869,7 +920,7 @@ __device__ __forceinline__ void scan_small_expanded(const double (&ax)[PPL], con
 // 4 rows per lane in order, wave butterfly, waves in order; chunks in order), so a registration computed here is
 // bit-identical to the same registration run through icp_amd_run.
 template <int PPL, int MODE>
-__global__ __launch_bounds__(kWG) void batch_icp_kernel(const double *__restrict__ P_in, const double *__restrict__ Q_in, unsigned n,
+__global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(PPL == 4 ? 3 : 2))) void batch_icp_kernel(const double *__restrict__ P_in, const double *__restrict__ Q_in, unsigned n,
                                                         unsigned m, unsigned m_pad, unsigned iters, double *__restrict__ P_out,
                                                         double *__restrict__ rec_out, uint32_t *__restrict__ idx_out)
 {

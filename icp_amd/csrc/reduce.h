@@ -39,7 +39,7 @@ __device__ __forceinline__ double block_sum(double (&v)[NV], double *smem)
 // records that is the plain in-order sum.  The groups of one pass are summed by different threads at the same time, so
 // the dependent add chain is kSumGroup + count / kSumGroup long instead of count.
 constexpr int kSumGroup = 32;
-template <int W, int TB>   // TB = threads of the workgroup; stage holds TB doubles
+template <int W, int TB, int BATCH = kSumGroup>   // TB = threads of the workgroup (stage holds TB doubles); BATCH = loads in flight per thread
 __device__ __forceinline__ double ordered_sum(const double *__restrict__ partial, size_t count, double *stage)
 {
     constexpr int GP = TB / W;   // groups per pass
@@ -53,12 +53,15 @@ __device__ __forceinline__ double ordered_sum(const double *__restrict__ partial
             const size_t r0 = g * kSumGroup;
             const int recs = (int)((count - r0 < (size_t)kSumGroup) ? (count - r0) : (size_t)kSumGroup);
             const double *src = partial + r0 * W + col;
-            if (recs == kSumGroup) {   // every load of the group in flight before the first add: one memory latency, not four
-                double v[kSumGroup];
+            if (recs == kSumGroup) {   // the loads of the group in flight before the first add (BATCH at a time: registers); the adds in index order
 #pragma unroll
-                for (int r = 0; r < kSumGroup; ++r) v[r] = src[(size_t)r * W];
+                for (int r0b = 0; r0b < kSumGroup; r0b += BATCH) {
+                    double v[BATCH];
 #pragma unroll
-                for (int r = 0; r < kSumGroup; ++r) s += v[r];
+                    for (int r = 0; r < BATCH; ++r) v[r] = src[(size_t)(r0b + r) * W];
+#pragma unroll
+                    for (int r = 0; r < BATCH; ++r) s += v[r];
+                }
             } else {
 #pragma unroll 8
                 for (int r = 0; r < recs; ++r) s += src[(size_t)r * W];

@@ -429,7 +429,7 @@ def test_cli_five_column_cloud_aborts_like_the_reference(tmp_path):
 
 def test_device_svd_against_numpy_on_random_and_degenerate_covariances():
     """icp_amd_solve (the one-sided Jacobi of kernels.hip) against numpy.linalg.svd -- LAPACK gesdd, an algorithm that shares
-    nothing with the device's or the oracle's Jacobi -- on covariances no fixture holds: random, ill-conditioned,
+    nothing with the device's or the oracle's Jacobi -- on covariances no fixture holds: random (scales 1e-286 ... 1e286), ill-conditioned,
     negative-determinant (R = U V^T is then a reflection: the reference has no det fix, src/cpu/icp.cpp:218-221), rank 2 and
     rank 1.  S within 1e-9 of S0; R = U V^T within 1e-9 wherever it is unique (S2 > 1e-6 S0); for rank-2 input R is unique up
     to the sign of u3 v3^T; R is orthogonal in every case and t = Qc - Pc R^T."""
@@ -439,8 +439,8 @@ def test_device_svd_against_numpy_on_random_and_degenerate_covariances():
         U, _ = np.linalg.qr(rng.standard_normal((3, 3)))
         V, _ = np.linalg.qr(rng.standard_normal((3, 3)))
         kind = k % 5
-        if kind == 0:
-            A = rng.standard_normal((3, 3)) * 10.0 ** rng.uniform(-6, 6)
+        if kind == 0:   # any scale: the device scales the matrix by a power of two first, so no square under- or overflows
+            A = rng.standard_normal((3, 3)) * 10.0 ** rng.uniform(-6, 6) * (10.0 ** rng.choice([-280, -150, 0, 0, 150, 280]) if k % 10 == 0 else 1.0)
         elif kind == 1:   # ill-conditioned but nonsingular
             A = U @ np.diag([1.0, 10.0 ** rng.uniform(-5, 0), 10.0 ** rng.uniform(-5.5, -5)]) @ V.T * 10.0 ** rng.uniform(-3, 3)
         elif kind == 2:   # negative determinant
