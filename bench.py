@@ -466,10 +466,12 @@ def main():
         td.all_reduce(buf, op=td.ReduceOp.SUM)
         return [float(v) for v in buf.cpu()]
 
-    def run(search, steps, warmup, repeats=0, extras=False, block_times=False):
+    def run(search, steps, warmup, repeats=0, extras=False, block_times=False, kernel_timing=True):
         """`steps` timed iterations after `warmup` untimed ones.  Returns a dict: seconds (max over ranks), the search
-        kernel's average launch ms (this rank's and every rank's), geometry, the last iteration's outputs, ..."""
-        runner = icpdist.ShardedIcp(P, Q, rank=rank, world=world, device=local_rank, search=search, kernel_timing=True,
+        kernel's average launch ms (this rank's and every rank's), geometry, the last iteration's outputs, ...
+        block_times (the grid legs, whose iteration is tens of microseconds): the iterations run ten at a time through
+        ShardedIcp.steps -- on one rank the engine's own loop, one call across the C ABI per ten iterations."""
+        runner = icpdist.ShardedIcp(P, Q, rank=rank, world=world, device=local_rank, search=search, kernel_timing=kernel_timing,
                                     force_collective=force_pg)
         runner.begin()
         first_ms = None
@@ -482,17 +484,22 @@ def main():
                 runner.step()
                 barrier()
                 first_ms = max(all_ranks((time.perf_counter() - t1) * 1e3))
-            else:
+            elif not block_times:
                 runner.step()
+        if block_times and warmup > 1:
+            runner.steps(warmup - 1)
         barrier()
         runner.engine.kernel_ms()             # drop the warm-up launches from the kernel timer
         t0 = time.perf_counter()
         blocks = []
-        for k in range(steps):
-            runner.step()
-            if block_times and (k + 1) % 10 == 0:   # the grid leg: how the step time develops while the clouds converge
+        if block_times:   # the grid legs: how the step time develops while the clouds converge
+            for k in range(0, steps, 10):
+                runner.steps(min(10, steps - k))
                 barrier()
                 blocks.append(time.perf_counter())
+        else:
+            for k in range(steps):
+                runner.step()
         barrier()
         dt = time.perf_counter() - t0
         dt = max(all_ranks(dt))
@@ -549,8 +556,12 @@ def main():
         # two measurements: the first g_steps iterations of a registration (the clouds still move, search boxes are wide,
         # few rows hold a motion certificate) and g_steps iterations after 3 x g_steps more (the registration has settled:
         # what a long run spends most of its iterations in)
-        early = run("grid", g_steps, max(args.warmup, 3), block_times=True)
-        gr = run("grid", g_steps, max(args.warmup, 3) + 3 * g_steps, block_times=True)
+        # (step times from engines without per-launch events -- two event records are 10 % of a 50 us iteration -- and the
+        # search kernel's own time from a second pass with them)
+        early = run("grid", g_steps, max(args.warmup, 3), block_times=True, kernel_timing=False)
+        gr = run("grid", g_steps, max(args.warmup, 3) + 3 * g_steps, block_times=True, kernel_timing=False)
+        early["avg_ms"] = run("grid", g_steps, max(args.warmup, 3), block_times=True)["avg_ms"]
+        gr["avg_ms"] = run("grid", g_steps, max(args.warmup, 3) + 3 * g_steps, block_times=True)["avg_ms"]
         g_dt, g_ms, g_geo, g_stats = gr["dt"], gr["avg_ms"], gr["geo"], gr["grid_stats"]
         grid = {"ms_per_step": g_dt / g_steps * 1e3, "iters_per_sec": g_steps / g_dt, "steps": g_steps,
                 "warmup_steps": max(args.warmup, 3) + 3 * g_steps,

@@ -92,6 +92,15 @@ class ShardedIcp:
             if self.collective:
                 exchange_partials(self.cen, CEN_W, self.rank, self.world, self.group, force=True)
 
+    def steps(self, k):
+        """k iterations.  Without an exchange (one rank) that is the engine's own loop -- one call across the C ABI, as a host
+        program would make it -- instead of three calls per iteration from Python."""
+        if not self.collective:
+            self.engine.iterate(k)
+        else:
+            for _ in range(k):
+                self.step()
+
     def gather_source(self):
         """The registered cloud, assembled on every rank (host arrays)."""
         local = self.engine.get_source()      # synchronises the engine's stream

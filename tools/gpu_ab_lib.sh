@@ -1,6 +1,9 @@
 #!/bin/bash
 # A/B of two builds of the library on one box: icp_amd/libicp_amd_old.so (ICP_AMD_LIB) against the tree's own -- the batch
 # bench, the small-cloud probe, a 1M x 1M registration by tens of iterations.   usage: tools/gpu_ab_lib.sh <tag>
+# The baseline is built beforehand, here on the CPU box, from the commit to compare against:
+#   git worktree add /tmp/base <commit> && make -C /tmp/base icp_amd/libicp_amd.so && cp /tmp/base/icp_amd/libicp_amd.so icp_amd/libicp_amd_old.so
+# (git-ignored; it travels to the GPU box with the tree)
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-/root/repo}
 TAG=${1:-ab_lib}
