@@ -113,8 +113,8 @@ def grid_roofline(n_local, kernel_ms, step_s, world):
             "iteration_frac_of_measured_copy_rate": it / (MEASURED_COPY_TBPS * 1e12),
             "measured_stream_rates_tbps": {"copy": MEASURED_COPY_TBPS, "two_reads_one_write": MEASURED_2R1W_TBPS,
                                            "source": "tools/ubench_stream.hip at 1M rows, profiles/r3_ubench_stream.txt"},
-            "note": "`iteration_*`: the three launches of a settled iteration that move rows (search + covariance 100 B per row, "
-                    "apply 64) against the whole step time, which also holds the solve (10 us) and the centroid launch (4 us)"}
+            "note": "`iteration_*`: the two launches of a settled iteration that move rows (search + centroid + covariance 100 B per "
+                    "row, apply 64) against the whole step time, which also holds the one-workgroup solve (10 us)"}
 
 
 def fp64_variants(P, Q, device, steps=3):

@@ -1312,7 +1312,9 @@ extern "C" int icp_amd_batch_run(icp_amd_batch *b, unsigned iters, int search_va
         HIPCHK(hipEventCreate(&z));
         HIPCHK(hipEventRecord(a, b->stream));
     }
-    hipError_t er = batch_icp(b->stream, variant, b->P_in, b->Q_in, b->batch, b->n, b->m, iters, b->P_out, b->rec, b->idx);
+    icp_amd_options none{};
+    const bool strict = strict_requested(none);   // ICP_AMD_STRICT_ORDER=1: sequential centroid / covariance sums (kernels.hip)
+    hipError_t er = batch_icp(b->stream, variant, strict, b->P_in, b->Q_in, b->batch, b->n, b->m, iters, b->P_out, b->rec, b->idx);
     if (er == hipSuccess && elapsed_ms) {
         er = hipEventRecord(z, b->stream);
         if (er == hipSuccess) er = hipEventSynchronize(z);

@@ -711,8 +711,6 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
     ctx.eval_cap = eval_cap; ctx.defer_always = defer_always; ctx.ovf_count = ovf_count; ctx.ovf_list = ovf_list; ctx.out_rec = out_rec;
     ctx.mot = mot; ctx.stat = stat; ctx.pc[0] = pc[0]; ctx.pc[1] = pc[1]; ctx.pc[2] = pc[2];
     // Rows that walk are rare once certificates hold, but nearly every wave has a few, and a wave is as slow as its slowest
-    // lane: the workgroup gathers its walking rows and packs them into as few waves as they need; the other waves leave.
-    // Rows that walk are rare once certificates hold, but nearly every wave has a few, and a wave is as slow as its slowest
     // lane: the workgroup gathers its walking rows -- with the state their lane has already computed: reading the record and
     // deciding again was 4 us of an iteration while rows walk -- and packs them into as few waves as they need; the other
     // waves leave.  (Packing them in the order of their search radius, so that a wave's rows have boxes of about one size,
@@ -767,7 +765,8 @@ __device__ __forceinline__ void cov_row_sums(unsigned m, double reject_d2, doubl
 // storage order, four rows per lane with all eight record loads in flight, exactly the shape of cov_rec_kernel
 // (kernels.hip), whose outputs this kernel writes too: idx_out and the chunk's partial sums, same arithmetic in the same
 // order, bit for bit.  A launch of this kernel therefore replaces search_grid_kernel AND cov_rec_kernel (64 of an
-// iteration's 228 bytes per row, and a launch).  Rows whose certificate does not hold walk the cells as in
+// iteration's 228 bytes per row, and a launch) -- and, when cen_part is given, finalize_centroid_kernel as well.
+// 128 registers = 4 waves per SIMD: the 977 workgroups of a 1M-row cloud are resident at once.  Rows whose certificate does not hold walk the cells as in
 // search_grid_kernel (the workgroup's lanes share them out; nothing is handed to the overflow kernel: ctx.ovf_list is null),
 // and the lanes that own those rows read the results back before the sums are formed.  The host launches it when the previous
 // search reported a settled registration (a mapped word, possibly a launch old): the choice never changes a result.

@@ -241,7 +241,7 @@ hipError_t apply(hipStream_t s, Soa3 P, size_t n, const double *solve_rec, doubl
 constexpr size_t kBatchMaxN = 2048;
 constexpr size_t kBatchMaxM = 4096;
 size_t batch_lds_bytes(size_t m);
-hipError_t batch_icp(hipStream_t s, int variant, const double *P_in, const double *Q_in, size_t batch, size_t n, size_t m,
+hipError_t batch_icp(hipStream_t s, int variant, bool strict, const double *P_in, const double *Q_in, size_t batch, size_t n, size_t m,
                      unsigned iters, double *P_out, double *rec_out, uint32_t *idx_out);
 
 // test hook: key[i] = sqrt(sqrt(d2[i])) computed on the device

@@ -919,7 +919,11 @@ __device__ __forceinline__ void scan_small_expanded(const double (&ax)[PPL], con
 // solve -> apply runs `iters` times without touching HBM.  All reductions have the shape the engine uses (1024-row chunks:
 // 4 rows per lane in order, wave butterfly, waves in order; chunks in order), so a registration computed here is
 // bit-identical to the same registration run through icp_amd_run.
-template <int PPL, int MODE>
+// STRICT (ICP_AMD_STRICT_ORDER=1; difference form on SoA targets only): the three centroids' and the nine covariance sums run
+// sequentially over the rows, one lane per output, as the reference's do (src/libalg/mean.cpp:106-131, src/cpu/icp.cpp:115-129)
+// and as the engine's strict order does (strict_centroid_kernel / strict_cov_kernel): Qc, Pc and cov carry the reference's
+// bits.  The running cloud and the indices are staged in LDS for that (3 n doubles + n words behind the solve record).
+template <int PPL, int MODE, bool STRICT = false>
 __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(PPL == 4 ? 3 : 2))) void batch_icp_kernel(const double *__restrict__ P_in, const double *__restrict__ Q_in, unsigned n,
                                                         unsigned m, unsigned m_pad, unsigned iters, double *__restrict__ P_out,
                                                         double *__restrict__ rec_out, uint32_t *__restrict__ idx_out)
@@ -932,11 +936,23 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(PPL == 4 ? 
     double *bc = red + 48;                  // [0..2] Pc, [4..15] cov sums, [16..18] Qc, [20..47] solve record
     constexpr int NCH = PPL / 4;            // 1024-row chunks covered by the PPL*256 slots
     const unsigned tid = threadIdx.x;
+    static_assert(!STRICT || MODE == kExact, "strict order reads the targets from the SoA layout");
+    const unsigned np = (n + 1u) & ~1u;     // STRICT: rows of the staged cloud (sp[k * np + i]), then the staged indices
+    double *sp = bc + 48;
+    uint32_t *sj = (uint32_t *)(sp + 3 * (size_t)np);
+    (void)sp; (void)sj;
     const double *Pb = P_in + (size_t)blockIdx.x * n * 3;
     const double *Qb = Q_in + (size_t)blockIdx.x * m * 3;
 
     // Q_center = Q.mean(0); Q -= Q_center (src/cpu/icp.cpp:197-198)
     double tq = 0.0;
+    if constexpr (STRICT) {
+        if (tid < 3) {
+            double r = 0.0;
+            for (unsigned j = 0; j < m; ++j) r += Qb[(size_t)j * 3 + tid];
+            bc[16 + tid] = r / (double)m;
+        }
+    } else
     for (unsigned c0 = 0; c0 < m; c0 += kChunk) {
         double acc[3] = {0.0, 0.0, 0.0};
 #pragma unroll
@@ -952,7 +968,7 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(PPL == 4 ? 
         const double t = block_sum<3>(acc, red);
         if (tid < 3) tq += t;
     }
-    if (tid < 3) bc[16 + tid] = tq / (double)m;
+    if (!STRICT && tid < 3) bc[16 + tid] = tq / (double)m;
     __syncthreads();
     const double qc0 = bc[16], qc1 = bc[17], qc2 = bc[18];
     double qn_max = 0.0;
@@ -1004,6 +1020,19 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(PPL == 4 ? 
     for (unsigned it = 0; it < iters; ++it) {
         // P_center = P_copy.mean(0) (src/cpu/icp.cpp:206)
         double tc = 0.0;
+        if constexpr (STRICT) {
+#pragma unroll
+            for (int s = 0; s < PPL; ++s) {
+                const unsigned i = s * kWG + tid;
+                if (i < n) { sp[i] = px[s]; sp[np + i] = py[s]; sp[2 * (size_t)np + i] = pz[s]; }
+            }
+            __syncthreads();
+            if (tid < 3) {
+                double r = 0.0;
+                for (unsigned i = 0; i < n; ++i) r += sp[tid * (size_t)np + i];
+                bc[tid] = r / (double)n;
+            }
+        } else
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
             double acc[3] = {0.0, 0.0, 0.0};
@@ -1020,7 +1049,7 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(PPL == 4 ? 
             const double t = block_sum<3>(acc, red);
             if (tid < 3) tc += t;
         }
-        if (tid < 3) bc[tid] = tc / (double)n;
+        if (!STRICT && tid < 3) bc[tid] = tc / (double)n;
         __syncthreads();
         const double c0 = bc[0], c1 = bc[1], c2 = bc[2];
 
@@ -1068,6 +1097,27 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(PPL == 4 ? 
             if (tid < kCovW) tv += t;
         }
         if (tid < kCovW) bc[4 + tid] = tv;
+        if constexpr (STRICT) {   // the nine sums again, row by row (slot 9, the sum of d^2 behind the rms, keeps the tree's value)
+#pragma unroll
+            for (int s = 0; s < PPL; ++s) {
+                const unsigned i = s * kWG + tid;
+                if (i < n) sj[i] = bj[s];
+            }
+            __syncthreads();
+            if (tid < 9) {
+                const unsigned a = tid / 3, b = tid % 3;
+                const double cb = bc[b];
+                const double *qa = a == 0 ? sx : (a == 1 ? sy : sz);
+                double cov = 0.0;
+                for (unsigned i = 0; i < n; ++i) {
+                    const uint32_t j = sj[i];
+                    if (!(j < m)) continue;
+                    const double p = sp[b * (size_t)np + i] - cb;
+                    cov = cov + qa[j] * p;
+                }
+                bc[4 + tid] = cov;
+            }
+        }
         __syncthreads();
         // svd, R, t (src/cpu/icp.cpp:218-223)
         if (tid == 0) solve_record(bc + 4, bc, bc + 16, (double)n, bc + 20);
@@ -1351,12 +1401,13 @@ hipError_t apply(hipStream_t s, Soa3 P, size_t n, const double *solve_rec, doubl
 
 size_t batch_lds_bytes(size_t m) { return (4 * ((m + 31) / 32 * 32) + 48 + 48) * sizeof(double); }   // the larger layout (records)
 
-template <int PPL, int MODE>
+template <int PPL, int MODE, bool STRICT>
 static hipError_t batch_launch(hipStream_t s, const double *P_in, const double *Q_in, size_t batch, size_t n, size_t m, unsigned iters,
                                double *P_out, double *rec_out, uint32_t *idx_out)
 {
-    const size_t lds = ((MODE == kExpanded ? 4 : 3) * ((m + 31) / 32 * 32) + 48 + 48) * sizeof(double);
-    auto kern = batch_icp_kernel<PPL, MODE>;
+    size_t lds = ((MODE == kExpanded ? 4 : 3) * ((m + 31) / 32 * 32) + 48 + 48) * sizeof(double);
+    if (STRICT) lds += 3 * ((n + 1) & ~(size_t)1) * sizeof(double) + ((n + 1) & ~(size_t)1) * sizeof(uint32_t);
+    auto kern = batch_icp_kernel<PPL, MODE, STRICT>;
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
@@ -1365,14 +1416,18 @@ static hipError_t batch_launch(hipStream_t s, const double *P_in, const double *
                                            idx_out);
 }
 
-hipError_t batch_icp(hipStream_t s, int variant, const double *P_in, const double *Q_in, size_t batch, size_t n, size_t m,
+hipError_t batch_icp(hipStream_t s, int variant, bool strict, const double *P_in, const double *Q_in, size_t batch, size_t n, size_t m,
                      unsigned iters, double *P_out, double *rec_out, uint32_t *idx_out)
 {
     if (batch == 0 || n == 0 || m == 0 || n > kBatchMaxN || m > kBatchMaxM || batch > 0x7FFFFFFFu) return hipErrorInvalidValue;
+    if (strict) {   // the reference's reduction order: one instantiation per source size class (the indices do not depend on the variant)
+        if (n <= 1024) return batch_launch<4, kExact, true>(s, P_in, Q_in, batch, n, m, iters, P_out, rec_out, idx_out);
+        return batch_launch<8, kExact, true>(s, P_in, Q_in, batch, n, m, iters, P_out, rec_out, idx_out);
+    }
 #define ICPK_BATCH(PPL_) \
-    return variant == kExpanded ? batch_launch<PPL_, kExpanded>(s, P_in, Q_in, batch, n, m, iters, P_out, rec_out, idx_out) \
-           : variant == kFma    ? batch_launch<PPL_, kFma>(s, P_in, Q_in, batch, n, m, iters, P_out, rec_out, idx_out) \
-                                : batch_launch<PPL_, kExact>(s, P_in, Q_in, batch, n, m, iters, P_out, rec_out, idx_out)
+    return variant == kExpanded ? batch_launch<PPL_, kExpanded, false>(s, P_in, Q_in, batch, n, m, iters, P_out, rec_out, idx_out) \
+           : variant == kFma    ? batch_launch<PPL_, kFma, false>(s, P_in, Q_in, batch, n, m, iters, P_out, rec_out, idx_out) \
+                                : batch_launch<PPL_, kExact, false>(s, P_in, Q_in, batch, n, m, iters, P_out, rec_out, idx_out)
     if (n <= 1024) ICPK_BATCH(4);
     ICPK_BATCH(8);
 #undef ICPK_BATCH

@@ -44,6 +44,55 @@ def test_batch_of_golden_pairs():
         assert relerr(out["P_out"][0], g["P_out"]) < 1e-9
 
 
+def test_batch_strict_order_carries_the_reference_bits(monkeypatch):
+    """ICP_AMD_STRICT_ORDER=1 in the multi-registration kernel ("N <= 4096 and batch mode"): centroids and
+    covariance summed row by row, one lane per output.  The first iteration's covariance is then BIT-identical to the
+    reference's (src/cpu/icp.cpp:115-129 on centroids of src/libalg/mean.cpp:106-131) on every fixture the kernel can hold,
+    every registration equals the same pair through a strict-order engine bit for bit at any iteration (both source size
+    classes of the kernel, N != M), and without the switch the covariance is NOT the reference's everywhere."""
+    for name in ("c1_30pts", "syn256", "syn1k"):
+        g = golden(name)
+        monkeypatch.setenv("ICP_AMD_STRICT_ORDER", "1")
+        out = icp_amd.icp_gpu_batch(np.stack([g["P"], g["P"]]), np.stack([g["Q"], g["Q"]]), 1)
+        for b in range(2):
+            assert np.array_equal(out["cov"][b], g["cov"][0]), (name, b)
+            assert np.array_equal(out["idx"][b], g["idx"][0]), (name, b)
+        iters = int(g["iters"])
+        out = icp_amd.icp_gpu_batch(g["P"][None], g["Q"][None], iters)
+        monkeypatch.delenv("ICP_AMD_STRICT_ORDER")
+        e = icp_amd.Engine(search="f32", strict_order=True)
+        e.set_target(g["Q"])
+        e.set_source(g["P"])
+        e.iterate(iters)
+        last = e.get_last()
+        for k in ("cov", "R", "t", "idx"):
+            assert np.array_equal(out[k][0], last[k]), (name, k)
+        assert np.array_equal(out["P_out"][0], e.get_source()), name
+        e.close()
+        assert np.array_equal(out["idx"][0], g["idx"][-1]) and relerr(out["P_out"][0], g["P_out"]) < 1e-9
+    differs = 0
+    for n, m in ((1500, 3000), (2048, 4096), (700, 333)):
+        P, Q = synth.make_pair(n, max(n, m), seed=61, angle=0.1)
+        Q = Q[:m]
+        monkeypatch.setenv("ICP_AMD_STRICT_ORDER", "1")
+        out = icp_amd.icp_gpu_batch(np.stack([P, P[::-1]]), np.stack([Q, Q]), 3)
+        monkeypatch.delenv("ICP_AMD_STRICT_ORDER")
+        plain = icp_amd.icp_gpu_batch(P[None], Q[None], 3)
+        differs += not np.array_equal(plain["cov"][0], out["cov"][0])
+        assert relerr(plain["cov"][0], out["cov"][0]) < 1e-12 and np.array_equal(plain["idx"][0], out["idx"][0])
+        for b, Pb in enumerate((P, P[::-1])):
+            e = icp_amd.Engine(search="f32", strict_order=True)
+            e.set_target(Q)
+            e.set_source(np.ascontiguousarray(Pb))
+            e.iterate(3)
+            last = e.get_last()
+            for k in ("cov", "R", "t", "idx"):
+                assert np.array_equal(out[k][b], last[k]), (n, m, b, k)
+            assert np.array_equal(out["P_out"][b], e.get_source())
+            e.close()
+    assert differs   # the default tree and the sequential sums do not round alike everywhere
+
+
 def test_batch_variants_and_limits():
     P, Q = synth.make_batch(6, 500)
     b = icp_amd.Batch(6, 500, 500)
