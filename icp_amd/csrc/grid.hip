@@ -599,7 +599,8 @@ __device__ __forceinline__ void grid_row_walk(const GridCtx &ctx, GridRow &row)
 #pragma unroll
             for (int u = 1; u < ROWS; ++u) o[u] = kb[u] - ce[u - 1];
             for (uint32_t t = 0; t < total; t += FLIGHT) {
-                double4 v[FLIGHT];
+                double2 vxy[FLIGHT];   // the coordinates only (24 of the record's 32 bytes): the index is read for the winner alone
+                double vz[FLIGHT];
                 uint32_t kk[FLIGHT];
 #pragma unroll
                 for (int w = 0; w < FLIGHT; ++w) {
@@ -608,11 +609,13 @@ __device__ __forceinline__ void grid_row_walk(const GridCtx &ctx, GridRow &row)
 #pragma unroll
                     for (int u = ROWS - 2; u >= 0; --u) off = tt < ce[u] ? o[u] : off;
                     kk[w] = tt + off;
-                    v[w] = rec[kk[w]];
+                    const double *rp = (const double *)&rec[kk[w]];
+                    vxy[w] = *(const double2 *)rp;
+                    vz[w] = rp[2];
                 }
 #pragma unroll
                 for (int w = 0; w < FLIGHT; ++w) {
-                    const double dw = d2_exact(ax, ay, az, v[w].x, v[w].y, v[w].z);
+                    const double dw = d2_exact(ax, ay, az, vxy[w].x, vxy[w].y, vz[w]);
                     const double d = (w == 0 || t + w < total) ? dw : INFINITY;
                     d2 = __builtin_fmin(d2, __builtin_fmax(d, d1));
                     k1 = d < d1 ? kk[w] : k1;
@@ -667,8 +670,8 @@ __device__ __forceinline__ void grid_row_walk(const GridCtx &ctx, GridRow &row)
     if (stat) atomicAdd(&stat[1], (unsigned long long)evals);
 }
 
-template <int ROWS, int FLIGHT>
-__global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(5, 5))) void search_grid_kernel(const double *__restrict__ px, const double *__restrict__ py,
+template <int ROWS, int FLIGHT, int WAVES>
+__global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void search_grid_kernel(const double *__restrict__ px, const double *__restrict__ py,
                                                           const double *__restrict__ pz, double *__restrict__ pc_io, size_t n,
                                                           GridDesc g, const uint32_t *__restrict__ start,
                                                           const double4 *__restrict__ rec,
@@ -1145,9 +1148,11 @@ hipError_t search_grid(hipStream_t s, Soa3 P, size_t n, double *pc, const Grid &
     unsigned long long *stat = (all && all->stat) ? all->stat + 2 * (all->stat_slot++ % kStatSlots) : nullptr;
     uint32_t *hint = (all && all->host_count) ? all->host_count + 1 : nullptr;
     if (!P.rec) motion = nullptr;   // certificates live in the source records
-    // Rows per group x loads in flight: 4 x 4.  Measured against 4 x 8, 8 x 4 and 8 x 8 (profiles/r2_v2_grid_shape_ab.txt): eight
-    // loads in flight are 9-12 % slower everywhere (registers: 4 or 3 waves per SIMD instead of 5, and more masked slots),
-    // eight rows per group are equal on volumes and 10 % faster only on the first searches of a 1M-point sheet.
+    // Rows per group x loads in flight: 4 x 6 at 4 waves per SIMD.  Round 2 measured 4 x 4 (5 waves) against 4 x 8, 8 x 4 and 8 x 8
+    // with whole 32-byte records in flight (profiles/r2_v2_grid_shape_ab.txt): eight loads were 9-12 % slower everywhere
+    // (registers: 4 or 3 waves per SIMD, more masked slots), eight rows per group equal on volumes.  With only the 24 bytes of
+    // coordinates in flight per candidate (round 3), six loads fit 110 registers and are 2-3.5 % faster than four while rows
+    // walk; eight (126 registers) measure between the two (profiles/r3_flight_ab.txt).  ICP_AMD_DEBUG=grid_flight=4|6|8.
     const bool settled_launch = fused && fused->idx_out && fused->partial && all && all->fuse_cov && hint && all->host_mem[1] == 1u &&
                                 P.rec && idx_prev && motion;
     // cen_part: the launch is asked to finish the centroid itself.  The settled kernel does that behind its row loads for any
@@ -1172,7 +1177,9 @@ hipError_t search_grid(hipStream_t s, Soa3 P, size_t n, double *pc, const Grid &
     }
     static const int xcd_map = knob_int("grid_xcd", 1);
     const size_t wgs_rows = (n + kWG - 1) / kWG;
-    hipError_t e = launch(search_grid_kernel<4, 4>, dim3((unsigned)(xcd_map ? (wgs_rows + 7) / 8 * 8 : wgs_rows)), dim3(kWG), 0, s, P.x, P.y,
+    static const int flight = knob_int("grid_flight", 6);
+    auto kern = flight >= 8 ? search_grid_kernel<4, 8, 4> : flight >= 6 ? search_grid_kernel<4, 6, 4> : search_grid_kernel<4, 4, 5>;
+    hipError_t e = launch(kern, dim3((unsigned)(xcd_map ? (wgs_rows + 7) / 8 * 8 : wgs_rows)), dim3(kWG), 0, s, P.x, P.y,
                           P.z, pc, n, g.d, g.start, g.rec, Qz.x, Qz.y, Qz.z, Qz.rec, (unsigned)m, idx_prev, P.rec, P.rec_stride, order,
                           row_cap, (unsigned)eval_cap, sc ? sc->defer_always : 0, cnt, sc ? sc->list : nullptr, out_rec, motion,
                           order_switch, stat, cen_part, (unsigned)cen_chunks, cen_denom, xcd_map, hint);
