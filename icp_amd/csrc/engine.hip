@@ -147,7 +147,7 @@ struct icp_amd_engine {
     bool mfma16 = false;        // ... on the fp16 K = 16 MFMA (operands in two fp16 pieces), needs qrec16
     void *qrec16 = nullptr;     // 2 * m_pad 16-byte halves of the fp16 target records (built when that filter is selected)
     bool qrec16_ok = false;
-    bool fuse_centroid = true;  // grid search on a cloud of few chunks finishes the centroid itself (no finalize_centroid launch)
+    bool fuse_centroid = true;  // the grid search finishes the centroid itself where that pays (search_grid() decides; kernels.h)
     bool qrec_ok = false;       // qrec / qmax / f32_ok describe the current target (built with it, or by the first brute-force launch)
     Grid grid;                  // uniform grid over Qz (search variant GRID); built on first use per target
     bool grid_built = false;
@@ -643,7 +643,7 @@ extern "C" int icp_amd_step_search(icp_amd_engine *e)
     HIPCHK(set_device(e->opt.device));
     double *cov_slot = e->cov_part + (size_t)e->opt.rank * e->cpr * kCovW;
     // P_center = P_copy.mean(0) (src/cpu/icp.cpp:206): chunk partials of every rank, summed in index order -- by a launch of
-    // its own, or (grid search on a cloud of few chunks) by the search kernel itself
+    // its own, or (grid search: the settled kernel, or any search of a cloud of few chunks) by the search kernel itself
     if (!e->n) HIPCHK(finalize_centroid(e->stream, e->cen_part, e->total_chunks, (double)e->n_global, e->pc));
     if (e->n) {
         hipEvent_t a = nullptr, b = nullptr;
