@@ -1177,7 +1177,7 @@ hipError_t search_grid(hipStream_t s, Soa3 P, size_t n, double *pc, const Grid &
     }
     static const int xcd_map = knob_int("grid_xcd", 1);
     const size_t wgs_rows = (n + kWG - 1) / kWG;
-    static const int flight = knob_int("grid_flight", 6);
+    const int flight = all ? all->flight : 6;   // read when the scratch was allocated (grid_flight)
     auto kern = flight >= 8 ? search_grid_kernel<4, 8, 4> : flight >= 6 ? search_grid_kernel<4, 6, 4> : search_grid_kernel<4, 4, 5>;
     hipError_t e = launch(kern, dim3((unsigned)(xcd_map ? (wgs_rows + 7) / 8 * 8 : wgs_rows)), dim3(kWG), 0, s, P.x, P.y,
                           P.z, pc, n, g.d, g.start, g.rec, Qz.x, Qz.y, Qz.z, Qz.rec, (unsigned)m, idx_prev, P.rec, P.rec_stride, order,
@@ -1207,6 +1207,7 @@ hipError_t grid_scratch_alloc(hipStream_t s, size_t n, GridScratch *sc)
         if (e == hipSuccess) e = hipMemsetAsync(sc->stat, 0, 2 * kStatSlots * sizeof(unsigned long long), s);
     }
     sc->fuse_cov = knob_int("grid_fuse_cov", 1);
+    sc->flight = knob_int("grid_flight", 6);
     if (e == hipSuccess) e = hipHostMalloc((void **)&sc->host_mem, 2 * sizeof(uint32_t), hipHostMallocMapped);
     if (e == hipSuccess) {
         sc->host_mem[0] = 0;

@@ -151,6 +151,7 @@ struct GridScratch {
                                             // registration settled (hints for the host's next launch, read without synchronisation)
     uint32_t *host_count = nullptr;         // device address of the same two words
     int fuse_cov = 1;                       // ICP_AMD_GRID_FUSE_COV=0: never the settled search that also forms the covariance sums
+    int flight = 6;                         // candidate loads in flight per walking lane of search_grid_kernel (grid_flight=4|6|8)
     int parity = 0;
     int row_cap = 64, eval_cap = 768;       // rows of cells / targets one lane walks alone (read from the environment at allocation)
     int defer_always = 0;                   // 1: hand over every box above the caps (tests); 0: only when most of the wave would idle

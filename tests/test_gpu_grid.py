@@ -440,3 +440,38 @@ def test_settled_search_that_also_forms_the_covariance_changes_nothing(monkeypat
             for x, y in zip(a[0][it], b[0][it]):
                 assert np.array_equal(x, y), (len(P), switch, it)
         assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and a[3] == b[3]
+
+
+def test_candidate_loads_in_flight_change_nothing(monkeypatch):
+    """search_grid_kernel has three instantiations -- 4, 6 (default) or 8 candidate loads in flight per walking lane
+    (ICP_AMD_DEBUG=grid_flight) -- that differ in how a lane's flattened candidate sequence is cut into batches (and in the masked
+    slots at its end).  Same indices every iteration, same final cloud bit for bit, and the same as brute force: on a pair that
+    starts far off (every row walks, boxes of many sizes), a thin sheet (long runs), duplicated targets and a tiny cloud."""
+    rng = np.random.RandomState(9)
+    cases = [synth.make_pair(30000, 31000, seed=71, angle=0.5, t0=(0.3, -0.2, 0.1))]
+    sheet = rng.uniform(-1, 1, (20000, 3)) * np.array([1.0, 1.0, 1e-3])
+    cases.append((sheet[:15000] @ synth.rotation(0.08).T + 0.02, sheet))
+    P, Q = synth.make_pair(6000, 6000, seed=72, angle=0.2)
+    cases.append((P, np.concatenate([Q, Q[:3000]])))
+    cases.append(synth.make_pair(70, 1100, seed=73, angle=0.3))
+    for P, Q in cases:
+        runs = {}
+        for label, search, debug in (("4", "grid", "grid_flight=4"), ("6", "grid", None), ("8", "grid", "grid_flight=8"), ("brute", "f32", None)):
+            if debug:
+                monkeypatch.setenv("ICP_AMD_DEBUG", debug)
+            e = icp_amd.Engine(search=search)
+            e.set_target(Q)
+            e.set_source(P)
+            out = []
+            for _ in range(6):
+                e.iterate(1)
+                out.append(e.get_last()["idx"].copy())
+            runs[label] = (out, e.get_source())
+            e.close()
+            if debug:
+                monkeypatch.delenv("ICP_AMD_DEBUG")
+        for other in ("4", "8", "brute"):
+            for it in range(6):
+                assert np.array_equal(runs["6"][0][it], runs[other][0][it]), (len(P), other, it)
+            assert np.array_equal(runs["6"][1], runs[other][1]), (len(P), other)
+
