@@ -466,7 +466,7 @@ def main():
         td.all_reduce(buf, op=td.ReduceOp.SUM)
         return [float(v) for v in buf.cpu()]
 
-    def run(search, steps, warmup, repeats=0, extras=False, block_times=False, kernel_timing=True):
+    def run(search, steps, warmup, repeats=0, extras=False, block_times=False, kernel_timing=True, block=10):
         """`steps` timed iterations after `warmup` untimed ones.  Returns a dict: seconds (max over ranks), the search
         kernel's average launch ms (this rank's and every rank's), geometry, the last iteration's outputs, ...
         block_times (the grid legs, whose iteration is tens of microseconds): the iterations run ten at a time through
@@ -493,8 +493,8 @@ def main():
         t0 = time.perf_counter()
         blocks = []
         if block_times:   # the grid legs: how the step time develops while the clouds converge
-            for k in range(0, steps, 10):
-                runner.steps(min(10, steps - k))
+            for k in range(0, steps, block):
+                runner.steps(min(block, steps - k))
                 barrier()
                 blocks.append(time.perf_counter())
         else:
@@ -507,7 +507,7 @@ def main():
         res = {"dt": dt, "avg_ms": avg_ms, "launches": launches, "geo": runner.engine.search_geometry(),
                "last": runner.engine.get_last(), "n_local": runner.n_local, "grid_stats": runner.engine.grid_stats(),
                "first_ms": first_ms, "rank_ms": all_ranks(avg_ms),
-               "ms_per_step_by_10": [round((b - a) * 100.0, 4) for a, b in zip([t0] + blocks[:-1], blocks)]}
+               "ms_per_step_by_10": [round((b - a) * 1e3 / block, 4) for a, b in zip([t0] + blocks[:-1], blocks)] if block == 10 else None}
         # outside the timed region: a few more steps, each bracketed on its own, for the spread (median + min)
         for _ in range(repeats):
             barrier()
@@ -559,7 +559,9 @@ def main():
         # (step times from engines without per-launch events -- two event records are 10 % of a 50 us iteration -- and the
         # search kernel's own time from a second pass with them)
         early = run("grid", g_steps, max(args.warmup, 3), block_times=True, kernel_timing=False)
-        gr = run("grid", g_steps, max(args.warmup, 3) + 3 * g_steps, block_times=True, kernel_timing=False)
+        # (the settled leg as ONE call of g_steps iterations: a barrier + synchronize every ten iterations, which the early leg
+        # pays to show how the step time develops, costs a 50 us iteration 3-6 % in refill gaps)
+        gr = run("grid", g_steps, max(args.warmup, 3) + 3 * g_steps, block_times=True, kernel_timing=False, block=g_steps)
         early["avg_ms"] = run("grid", g_steps, max(args.warmup, 3), block_times=True)["avg_ms"]
         gr["avg_ms"] = run("grid", g_steps, max(args.warmup, 3) + 3 * g_steps, block_times=True)["avg_ms"]
         g_dt, g_ms, g_geo, g_stats = gr["dt"], gr["avg_ms"], gr["geo"], gr["grid_stats"]
@@ -567,7 +569,6 @@ def main():
                 "warmup_steps": max(args.warmup, 3) + 3 * g_steps,
                 "speedup_vs_brute_force": (dt / args.steps) / (g_dt / g_steps), "search_kernel_avg_ms": g_ms,
                 "search": g_geo, "stats": g_stats, "first_step_ms": gr["first_ms"],
-                "ms_per_step_by_10": gr["ms_per_step_by_10"],
                 # HBM roofline of the settled grid search (hipEvent average over the timed launches).  Since round 3 that launch is
                 # search_grid_settled_kernel, which searches AND forms the covariance sums: 100 algorithmic bytes per source row --
                 # the row's two 32-byte record halves in, the match half out, 4 bytes of index out

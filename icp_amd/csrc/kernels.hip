@@ -494,15 +494,16 @@ __global__ __launch_bounds__(kWG) void cov_rec_kernel(const double4 *__restrict_
 // Directions of singular values at roundoff level (<= 1e-13 S[0]) are completed so that det(U) = det(V).
 //
 // One lane runs this while its launch waits, and a settled grid iteration is three such waits long, so the length of the
-// DEPENDENT chain of a rotation is what counts (measured: 10 us of a 24 us iteration on a 2 903-point cloud).  A rotation
-// therefore takes its reciprocal and its two inverse square roots from the hardware's seed instructions (v_rcp_f64 /
-// v_rsq_f64: 2^-23 relative by their specification) plus two Newton steps each -- about 1 ulp, 35 dependent instructions a
-// rotation where the correctly rounded divisions and roots of the textbook formulas need 87 -- and the convergence test
-// compares squares.  An error of an ulp in c, s or t only changes how completely this rotation annihilates its off-diagonal
-// element (the next sweep sees the rest); what the result's accuracy rests on -- the test itself, the final column norms and
-// the normalisation of U -- is computed with correctly rounded operations.  The matrix is scaled by a power of two to a
-// largest element in [1/2, 1) first (exact), so that no square under- or overflows for any input scale.
-__device__ __forceinline__ double rsqrt_2nr(double x)   // x in [1/4, 4]
+// DEPENDENT chain is what counts: a lone wave issues a dependent fp64 instruction every ~20 cycles (measured: 8 us of a 22 us
+// iteration on a 2 903-point cloud is this kernel).  Inverse square roots therefore come from the hardware's seed instruction
+// (v_rsq_f64: 2^-23 relative by its specification) plus two Newton steps -- about an ulp -- instead of a correctly rounded
+// root followed by a correctly rounded division: 30 dependent instructions a rotation where the textbook formulas need 87, and
+// the convergence test compares squares.  What the result's accuracy rests on: c^2 + s^2 = 1 in every rotation (both from one
+// inverse root, to an ulp), the convergence test, and unit columns of U (norms from refined inverse roots, a Gram-Schmidt pass
+// and a cross product).  The angle of a rotation only decides how much of its off-diagonal element is left for the next
+// sweep.  The matrix is scaled by a power of two to a largest element in [1/2, 1) first (exact), so that no square under- or
+// overflows for any input scale.
+__device__ __forceinline__ double rsqrt_2nr(double x)   // x in [1/4, 8]
 {
     double y = __builtin_amdgcn_rsq(x);
     double e = __builtin_fma(-(x * y), y, 1.0);
@@ -510,13 +511,11 @@ __device__ __forceinline__ double rsqrt_2nr(double x)   // x in [1/4, 4]
     e = __builtin_fma(-(x * y), y, 1.0);
     return __builtin_fma(0.5 * y, e, y);
 }
-__device__ __forceinline__ double rcp_2nr(double x)   // likewise
+__device__ __forceinline__ double rsqrt_1nr(double x)   // one step: 2^-45 relative, for a quantity that only steers an iteration
 {
-    double y = __builtin_amdgcn_rcp(x);
-    double e = __builtin_fma(-x, y, 1.0);
-    y = __builtin_fma(y, e, y);
-    e = __builtin_fma(-x, y, 1.0);
-    return __builtin_fma(y, e, y);
+    const double y = __builtin_amdgcn_rsq(x);
+    const double e = __builtin_fma(-(x * y), y, 1.0);
+    return __builtin_fma(0.5 * y, e, y);
 }
 
 // One rotation of columns P and Q of a (and of v): false = they are orthogonal already.
@@ -536,10 +535,11 @@ __device__ __forceinline__ bool jacobi_pair(double (&a)[9], double (&v)[9])
     const int e2 = __builtin_amdgcn_frexp_exp(__builtin_fmax(__builtin_fabs(d0), __builtin_fabs(g0)));
     const double d = __builtin_amdgcn_ldexp(d0, -e2), g2 = __builtin_amdgcn_ldexp(g0, -e2);
     const double x = d * d + g2 * g2;
-    const double h = x * rsqrt_2nr(x);
-    const double tt = (d >= 0.0 ? g2 : -g2) * rcp_2nr(__builtin_fabs(d) + h);
-    const double c = rsqrt_2nr(1.0 + tt * tt);
-    const double s = c * tt;
+    const double h = x * rsqrt_1nr(x);              // |(d, g)|: an error here only leaves a little of gamma for the next sweep
+    const double y = __builtin_fabs(d) + h;         // t = sign(d) g / y, so  c = 1 / sqrt(1 + t^2) = y / sqrt(y^2 + g^2),  s = c t:
+    const double r = rsqrt_2nr(y * y + g2 * g2);    // one inverse root (of a value in [1/4, 8)) gives both, to about an ulp --
+    const double c = y * r;                         // c^2 + s^2 = 1 is what keeps V orthogonal
+    const double s = (d >= 0.0 ? g2 : -g2) * r;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         double x0 = a[i * 3 + P], y0 = a[i * 3 + Q];
@@ -569,9 +569,21 @@ __device__ __forceinline__ void svd3(const double *A, double *U, double *S, doub
         const bool r12 = jacobi_pair<1, 2>(a, v);
         if (!(r01 || r02 || r12)) break;
     }
-    double sg[3];
+    // column norms of the scaled matrix and their reciprocals (one refined inverse root each; a column that vanishes next to
+    // the largest -- it is dropped below -- takes the library root)
+    double sg[3], rs[3];
     int ord[3] = {0, 1, 2};
-    for (int j = 0; j < 3; ++j) sg[j] = sqrt(a[j] * a[j] + a[3 + j] * a[3 + j] + a[6 + j] * a[6 + j]);   // of the scaled matrix
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const double ss = (a[j] * a[j] + a[3 + j] * a[3 + j]) + a[6 + j] * a[6 + j];
+        if (ss >= 0x1p-600 && ss < INFINITY) {
+            rs[j] = rsqrt_2nr(ss);
+            sg[j] = ss * rs[j];
+        } else {
+            rs[j] = 0.0;
+            sg[j] = sqrt(ss);
+        }
+    }
     for (int i = 0; i < 2; ++i)
         for (int j = 0; j < 2 - i; ++j)
             if (sg[ord[j]] < sg[ord[j + 1]]) {
@@ -587,7 +599,7 @@ __device__ __forceinline__ void svd3(const double *A, double *U, double *S, doub
         S[j] = __builtin_amdgcn_ldexp(sg[c], ex);
         for (int i = 0; i < 3; ++i) vv[i * 3 + j] = v[i * 3 + c];
         const bool ok = sg[c] > 0.0 && sg[c] > tol && rank == j;
-        for (int i = 0; i < 3; ++i) u[i * 3 + j] = ok ? a[i * 3 + c] / sg[c] : 0.0;
+        for (int i = 0; i < 3; ++i) u[i * 3 + j] = ok ? a[i * 3 + c] * rs[c] : 0.0;   // (ok: sg > 1e-13 of the largest, so rs is set)
         if (ok) rank = j + 1;
     }
     const double detv = vv[0] * (vv[4] * vv[8] - vv[5] * vv[7]) - vv[1] * (vv[3] * vv[8] - vv[5] * vv[6]) +
@@ -607,8 +619,8 @@ __device__ __forceinline__ void svd3(const double *A, double *U, double *S, doub
         }
         const double d01 = u[0] * u[1] + u[3] * u[4] + u[6] * u[7];
         for (int i = 0; i < 3; ++i) u[i * 3 + 1] -= d01 * u[i * 3];
-        const double n1 = sqrt(u[1] * u[1] + u[4] * u[4] + u[7] * u[7]);
-        for (int i = 0; i < 3; ++i) u[i * 3 + 1] /= n1;
+        const double n1 = rsqrt_2nr((u[1] * u[1] + u[4] * u[4]) + u[7] * u[7]);   // the squared norm is ~1 (rank 1: >= 2/3)
+        for (int i = 0; i < 3; ++i) u[i * 3 + 1] *= n1;
         const double w[3] = {u[3] * u[7] - u[6] * u[4], u[6] * u[1] - u[0] * u[7], u[0] * u[4] - u[3] * u[1]};
         double s3 = detv < 0 ? -1.0 : 1.0;
         if (rank == 3) s3 = (w[0] * u[2] + w[1] * u[5] + w[2] * u[8]) < 0 ? -1.0 : 1.0;
@@ -647,7 +659,7 @@ __device__ __forceinline__ void solve_extra(const double *out, const double *pc,
             g -= (a == b) ? 1.0 : 0.0;
             defect += g * g;
         }
-    extra[3] = sqrt(defect);
+    extra[3] = __builtin_amdgcn_sqrt(defect);   // compared with a threshold only: the hardware's approximate root (2^-23 relative)
 }
 
 // One workgroup of kSolveWG threads: the fixed-order sum of all chunk partials (one pass of ordered_sum up to
