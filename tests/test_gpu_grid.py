@@ -183,8 +183,8 @@ def test_grid_overflow_queue_and_auto_fallback(monkeypatch):
         e = icp_amd.Engine(search=search)
         e.set_target(Ql)
         e.set_source(Pl)
-        for _ in range(6):
-            e.iterate(1)
+        for _ in range(10):   # (the queue passes n / 8, where AUTO switches, around the fifth search; how many rows a wave hands over
+            e.iterate(1)      # depends on which rows share it, i.e. on the order the walking rows were packed in)
             e.sync()
         outs.append((e.get_last()["idx"], e.get_source()))
         stats[search] = e.grid_stats()
