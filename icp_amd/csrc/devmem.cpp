@@ -198,10 +198,40 @@ static hipError_t release(void *p, bool whole_device, hipStream_t s)
     return hipSuccess;
 }
 
+// Pinned host buffers of kPinBytes for staging small copies (engine.hip: copy_in / copy_out): pinning is the expensive part,
+// so released buffers are kept (at most eight, none with ICP_AMD_CACHE_MB=0) and handed to the next engine.
+static std::vector<void *> g_pins;   // under g_mu
+hipError_t pin_acquire(void **p)
+{
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        if (!g_pins.empty()) {
+            *p = g_pins.back();
+            g_pins.pop_back();
+            return hipSuccess;
+        }
+    }
+    return hipHostMalloc(p, kPinBytes, hipHostMallocDefault);
+}
+void pin_release(void *p)
+{
+    if (!p) return;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        if (cache_cap() && g_pins.size() < 8) {
+            g_pins.push_back(p);
+            return;
+        }
+    }
+    (void)hipHostFree(p);
+}
+
 void dcache_trim()
 {
     std::lock_guard<std::mutex> lk(g_mu);
     trim_locked(-1);
+    for (void *p : g_pins) (void)hipHostFree(p);
+    g_pins.clear();
 }
 
 size_t dcache_held()

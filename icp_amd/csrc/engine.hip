@@ -172,6 +172,8 @@ struct icp_amd_engine {
 
     double *stage = nullptr;    // AoS staging for uploads / downloads
     size_t stage_rows = 0;
+    void *pin = nullptr;        // pinned host staging for small copies to and from the caller's (pageable) buffers (copy_in)
+    bool pin_busy = false;      // a copy out of pin may still be in flight on the stream
 
     // search
     int variant = kExact, ppl = 4, q_splits = 1, q_splits_first = 1, cb = 8;
@@ -259,6 +261,7 @@ extern "C" int icp_amd_destroy(icp_amd_engine *e)
     free_dev(e, e->p_rec); free_dev(e, e->grid_out);
     if (e->own_part) { free_dev(e, e->cov_part); free_dev(e, e->cen_part); }
     if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
+    pin_release(e->pin);   // (the stream was synchronised above)
     delete e;
     return ICP_AMD_OK;
 }
@@ -274,10 +277,47 @@ static int ensure_stage(icp_amd_engine *e, size_t rows)
     return ICP_AMD_OK;
 }
 
+// Copies between the caller's buffers and the device.  The caller's memory is pageable, and below about half a megabyte the
+// runtime moves such a buffer at 3 GB/s (tools/ubench_h2d: 480 KB in 0.165 ms each way, 0.035 ms through pinned memory), up to
+// a few megabytes at a speed that depends on where the buffer lies (set_source of 48 485 rows: 0.37 ms, of 100 000: 0.13 ms):
+// clouds of up to kPinBytes (8 MB, 349 525 rows) go through a pinned buffer (devmem.cpp keeps them between engines); larger
+// ones, which the runtime moves at full speed, directly.  copy_in leaves the copy enqueued on the engine's stream (the
+// caller's buffer may be reused at once when staged); copy_out returns with the data in place.
+static int copy_in(icp_amd_engine *e, void *dev, const void *host, size_t bytes)
+{
+    if (bytes == 0) return ICP_AMD_OK;
+    if (bytes > kPinBytes) {
+        HIPCHK(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, e->stream));
+        return ICP_AMD_OK;
+    }
+    if (!e->pin) HIPCHK(pin_acquire(&e->pin));
+    if (e->pin_busy) HIPCHK(hipStreamSynchronize(e->stream));
+    memcpy(e->pin, host, bytes);
+    HIPCHK(hipMemcpyAsync(dev, e->pin, bytes, hipMemcpyHostToDevice, e->stream));
+    e->pin_busy = true;
+    return ICP_AMD_OK;
+}
+static int copy_out(icp_amd_engine *e, void *host, const void *dev, size_t bytes)
+{
+    if (bytes == 0 || bytes > kPinBytes) {
+        if (bytes) HIPCHK(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));
+        e->pin_busy = false;
+        return ICP_AMD_OK;
+    }
+    if (!e->pin) HIPCHK(pin_acquire(&e->pin));
+    HIPCHK(hipMemcpyAsync(e->pin, dev, bytes, hipMemcpyDeviceToHost, e->stream));   // stream order: behind any copy out of pin
+    HIPCHK(hipStreamSynchronize(e->stream));
+    e->pin_busy = false;
+    memcpy(host, e->pin, bytes);
+    return ICP_AMD_OK;
+}
+
 static int plan_search(icp_amd_engine *e);
 static int prepare_grid_source(icp_amd_engine *e);
 
 static const size_t kMaxRows = 0x7FFFFC00u;  // indices are 32-bit; padded sizes must fit too
+static const size_t kGridOrderMinRows = (size_t)1 << 18;   // source rows from which the grid search takes them in a spatial order
 static const size_t kStrictMaxSource = 4096, kStrictMaxTarget = (size_t)1 << 20;   // one lane sums these sequentially
 static bool strict_requested(const icp_amd_options &opt)
 {
@@ -326,7 +366,7 @@ extern "C" int icp_amd_set_target(icp_amd_engine *e, const double *Q, size_t m)
     }
     e->m = m;
     RCCHK(ensure_stage(e, m));
-    HIPCHK(hipMemcpyAsync(e->stage, Q, m * 3 * sizeof(double), hipMemcpyHostToDevice, e->stream));
+    RCCHK(copy_in(e, e->stage, Q, m * 3 * sizeof(double)));
     // Q_center = Q.mean(0); Q -= Q_center (reference src/cpu/icp.cpp:197-198), then SoA + inf padding
     const size_t chunks = (m + kChunk - 1) / kChunk;
     double *part = nullptr;
@@ -352,7 +392,10 @@ extern "C" int icp_amd_set_target(icp_amd_engine *e, const double *Q, size_t m)
     e->f32_ok = true;   // provisional until bruteforce_target() has seen the target's range
     e->qmax = 0.0;
     if (!wants_grid(e)) RCCHK(bruteforce_target(e));
-    else HIPCHK(hipStreamSynchronize(e->stream));   // the caller may reuse Q once this returns
+    else {
+        HIPCHK(hipStreamSynchronize(e->stream));   // the caller may reuse Q once this returns
+        e->pin_busy = false;
+    }
     e->have_target = true;
     grid_free(&e->grid);
     e->grid_built = false;
@@ -519,7 +562,12 @@ static int prepare_grid_source(icp_amd_engine *e)
             e->P.rec_stride = n_pad;
             HIPCHK(build_source_rec(e->stream, e->P, n));
         }
-        if (knob_int("grid_order", 1)) {
+        // The spatial order of the rows pays from a few hundred thousand rows on: below, the rows' cells share the L2 anyway, the
+        // iterations measure the same or slower with it (tools/order_small_probe.py: 100k rows x 20 iterations 0.86 ms without,
+        // 0.91 with; 300k: 1.53 / 1.43) and computing it is 0.1-0.15 ms of set_source -- a sixth of a whole registration of
+        // the cow pair.  grid_order=1 / 0 forces it on / off.
+        const int order_knob = knob_int("grid_order", -1);
+        if (order_knob > 0 || (order_knob < 0 && n >= kGridOrderMinRows)) {
             if (!e->order) HIPCHK(dmalloc(&e->order, n_pad * sizeof(uint32_t)));
             HIPCHK(grid_order(e->stream, e->P, n, e->order));
             e->order_ok = true;
@@ -581,13 +629,14 @@ extern "C" int icp_amd_set_source(icp_amd_engine *e, const double *P, size_t n)
     HIPCHK(hipMemsetAsync(cen_slot, 0, cpr * kCenW * sizeof(double), e->stream));
     if (n) {
         RCCHK(ensure_stage(e, n));
-        HIPCHK(hipMemcpyAsync(e->stage, P, n * 3 * sizeof(double), hipMemcpyHostToDevice, e->stream));
+        RCCHK(copy_in(e, e->stage, P, n * 3 * sizeof(double)));
     }
     HIPCHK(aos_to_soa(e->stream, e->stage, n, n_pad, nullptr, 0.0, e->P));
     e->soa_stale = false;
     RCCHK(prepare_grid_source(e));
     e->bf_left = e->bf_backoff = 0;
     HIPCHK(hipStreamSynchronize(e->stream));  // P may be reused by the caller after return
+    e->pin_busy = false;
     e->have_source = true;
     e->have_prev = false;
     e->cen_ready = false;
@@ -873,9 +922,8 @@ extern "C" int icp_amd_get_source(icp_amd_engine *e, double *P_out)
         RCCHK(ensure_stage(e, e->n));
         RCCHK(sync_soa(e));
         HIPCHK(soa_to_aos(e->stream, e->P, e->n, e->stage));
-        HIPCHK(hipMemcpyAsync(P_out, e->stage, e->n * 3 * sizeof(double), hipMemcpyDeviceToHost, e->stream));
     }
-    HIPCHK(hipStreamSynchronize(e->stream));
+    RCCHK(copy_out(e, P_out, e->stage, e->n * 3 * sizeof(double)));   // synchronises the stream
     return ICP_AMD_OK;
 }
 
@@ -886,8 +934,7 @@ extern "C" int icp_amd_get_last(icp_amd_engine *e, double *Pc, int32_t *idx, dou
     HIPCHK(set_device(e->opt.device));
     double rec[kSolveW];
     HIPCHK(hipMemcpyAsync(rec, e->rec, sizeof rec, hipMemcpyDeviceToHost, e->stream));
-    if (idx && e->n) HIPCHK(hipMemcpyAsync(idx, e->idx, e->n * sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(hipStreamSynchronize(e->stream));
+    RCCHK(copy_out(e, idx, e->idx, idx ? e->n * sizeof(uint32_t) : 0));   // synchronises the stream
     if (cov) memcpy(cov, rec, 9 * sizeof(double));
     if (S) memcpy(S, rec + 9, 3 * sizeof(double));
     if (R) memcpy(R, rec + 12, 9 * sizeof(double));

@@ -56,6 +56,10 @@ hipError_t dfree(void *p);
 // same, for a block that only work enqueued on stream `s` has touched: waits for that stream instead of the whole device,
 // so engines on other streams keep running (a batch of registrations on several host threads)
 hipError_t dfree_on(void *p, hipStream_t s);
+// a pinned host buffer of kPinBytes (kept and reused like the device blocks); release only when no copy through it is in flight
+constexpr size_t kPinBytes = (size_t)8 << 20;
+hipError_t pin_acquire(void **p);
+void pin_release(void *p);
 void dcache_trim();      // give every kept block back to the driver
 size_t dcache_held();    // bytes kept
 

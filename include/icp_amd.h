@@ -105,7 +105,9 @@ int         icp_amd_init(int device);
 /* Device memory released by the library (icp_amd_destroy, a cloud of another size, the one-shot calls) is kept for the
  * next request of about the same size instead of going back to the driver: hipFree costs 0.1 ms per block, a third of a
  * small one-shot registration.  ICP_AMD_CACHE_MB bounds what is kept (default 2048, 0 = keep nothing);
- * icp_amd_cache_trim returns it all to the driver now and reports how many bytes that was.  No reference counterpart. */
+ * icp_amd_cache_trim returns it all to the driver now and reports how many bytes that was.  Likewise the 8 MB pinned host
+ * buffers through which clouds of up to that size are copied (at most eight are kept; none with ICP_AMD_CACHE_MB=0; not
+ * counted in the bytes reported).  No reference counterpart. */
 size_t      icp_amd_cache_trim(void);
 /* rows per rank and 1024-row chunks per rank for a P-sharded run (pure host arithmetic). */
 size_t      icp_amd_rows_per_rank(size_t n_global, int world);
