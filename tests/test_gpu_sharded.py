@@ -149,6 +149,32 @@ def test_bench_two_ranks_on_one_gpu_over_gloo():
     assert d1["rms_last"] == d["rms_last"]
 
 
+def test_bench_batch_workload_split_over_two_ranks_over_gloo():
+    """BASELINE configs[4]'s multi-GPU leg in rehearsal: `bench.py --gpus 2 --workload batch` splits the registrations evenly
+    over the ranks (no data-path collective: a barrier and a MAX over the ranks' times are all that is exchanged), started
+    the way the driver starts it; two ranks on the one GPU of this box, gloo standing in for RCCL."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, ICP_AMD_BENCH_DEVICE="0", ICP_AMD_BENCH_BACKEND="gloo", OMP_NUM_THREADS="4")
+    env.pop("WORLD_SIZE", None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "batch", "--batch", "96", "--batch-n", "500",
+           "--batch-iters", "5", "--steps", "2", "--warmup", "1"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["config"]["parallelism"] == "batch-split2"
+    assert "48 per GPU" in d["config"]["workload"] and d["scaling"] == "strong"
+    # whole-job figures: all 96 registrations over the slowest rank's time
+    assert abs(d["registrations_per_sec"] - 96 * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["registrations_per_sec"]
+    assert abs(d["value"] - d["registrations_per_sec"] * 500 * 500 * 5) < 1e-6 * d["value"]
+    assert d["roofline"]["kernel"] == "batch_icp_kernel" and 0 < d["roofline"]["frac"] < 1.2 and d["cpu_baseline"] is None
+
+
 def test_bench_real_rccl_exchange_with_a_one_rank_process_group():
     """The exchange the multi-GPU benchmark relies on, executed for real on the one GPU of this box: ICP_AMD_BENCH_FORCE_PG=1
     makes bench.py create an RCCL process group of ONE rank (torch backend "nccl", device_id bound) and send the two
