@@ -776,6 +776,7 @@ extern "C" int icp_amd_step_search(icp_amd_engine *e)
             ++e->grid_since_source;
             // e->rec describes the motion since the previous search only if exactly one update ran in between.
             // Once the registration has settled the same launch also forms the covariance sums (grid.hip: settled search).
+            e->gscratch.issue_cert = e->grid_cert ? 1 : 0;
             fused.idx_out = e->idx;
             fused.reject_d2 = e->reject_d2;
             fused.partial = cov_slot;

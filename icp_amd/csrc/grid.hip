@@ -401,6 +401,7 @@ struct GridCtx {
     int row_cap;
     unsigned eval_cap;
     int defer_always;
+    int issue_cert;   // this search leaves a certificate with every row it walks (whether it may CHECK the previous search's is `mot`)
     uint32_t *ovf_count, *ovf_list;
     double2 *out_rec;
     const double *mot;
@@ -637,7 +638,7 @@ __device__ __forceinline__ void grid_row_walk(const GridCtx &ctx, GridRow &row)
             const double4 v = rec[k1];   // just read: the unique minimum
             bj = (uint32_t)__double_as_longlong(v.w);
             sqx = v.x; sqy = v.y; sqz = v.z;
-            if (mot) c = float_below(sqrt(__builtin_fmin(d2, Bfinal)) * (1.0 - 0x1p-50));   // a distance: s^2 <= every other target's computed d^2
+            if (ctx.issue_cert) c = float_below(sqrt(__builtin_fmin(d2, Bfinal)) * (1.0 - 0x1p-50));   // a distance: s^2 <= every other target's computed d^2
         } else {
             // near-ties: (key, index) among the targets inside the band, over the same box
             double bk = INFINITY;
@@ -681,7 +682,7 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(WAVES, WAVE
                                                           const uint32_t *__restrict__ idx_prev,
                                                           double4 *__restrict__ prec, size_t prec_stride,
                                                           const uint32_t *__restrict__ order,
-                                                          int row_cap, unsigned eval_cap, int defer_always,
+                                                          int row_cap, unsigned eval_cap, int defer_always, int issue_cert,
                                                           uint32_t *__restrict__ ovf_count,
                                                           uint32_t *__restrict__ ovf_list, double2 *__restrict__ out_rec,
                                                           const double *__restrict__ mot, double order_switch,
@@ -711,7 +712,7 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(WAVES, WAVE
     GridCtx ctx;
     ctx.px = px; ctx.py = py; ctx.pz = pz; ctx.g = g; ctx.start = start; ctx.rec = rec; ctx.qx = qx; ctx.qy = qy; ctx.qz = qz;
     ctx.qrec4 = qrec4; ctx.m = m; ctx.idx_prev = idx_prev; ctx.prec = prec; ctx.prec_stride = prec_stride; ctx.row_cap = row_cap;
-    ctx.eval_cap = eval_cap; ctx.defer_always = defer_always; ctx.ovf_count = ovf_count; ctx.ovf_list = ovf_list; ctx.out_rec = out_rec;
+    ctx.eval_cap = eval_cap; ctx.defer_always = defer_always; ctx.issue_cert = issue_cert; ctx.ovf_count = ovf_count; ctx.ovf_list = ovf_list; ctx.out_rec = out_rec;
     ctx.mot = mot; ctx.stat = stat; ctx.pc[0] = pc[0]; ctx.pc[1] = pc[1]; ctx.pc[2] = pc[2];
     // Rows that walk are rare once certificates hold, but nearly every wave has a few, and a wave is as slow as its slowest
     // lane: the workgroup gathers its walking rows -- with the state their lane has already computed: reading the record and
@@ -1148,6 +1149,10 @@ hipError_t search_grid(hipStream_t s, Soa3 P, size_t n, double *pc, const Grid &
     unsigned long long *stat = (all && all->stat) ? all->stat + 2 * (all->stat_slot++ % kStatSlots) : nullptr;
     uint32_t *hint = (all && all->host_count) ? all->host_count + 1 : nullptr;
     if (!P.rec) motion = nullptr;   // certificates live in the source records
+    // A search may CHECK the certificates of the previous one only when it knows the motion in between (`motion`); it ISSUES
+    // them whenever the caller keeps row records and has not switched them off -- also the first, un-seeded search of a
+    // source cloud, so that the second one already finds three quarters of its rows certified.
+    const int issue = (P.rec && all && all->issue_cert) ? 1 : 0;
     // Rows per group x loads in flight: 4 x 6 at 4 waves per SIMD.  Round 2 measured 4 x 4 (5 waves) against 4 x 8, 8 x 4 and 8 x 8
     // with whole 32-byte records in flight (profiles/r2_v2_grid_shape_ab.txt): eight loads were 9-12 % slower everywhere
     // (registers: 4 or 3 waves per SIMD, more masked slots), eight rows per group equal on volumes.  With only the 24 bytes of
@@ -1167,7 +1172,7 @@ hipError_t search_grid(hipStream_t s, Soa3 P, size_t n, double *pc, const Grid &
         GridCtx c{};
         c.px = P.x; c.py = P.y; c.pz = P.z; c.g = g.d; c.start = g.start; c.rec = g.rec; c.qx = Qz.x; c.qy = Qz.y; c.qz = Qz.z;
         c.qrec4 = Qz.rec; c.m = (unsigned)m; c.idx_prev = idx_prev; c.prec = P.rec; c.prec_stride = P.rec_stride; c.row_cap = row_cap;
-        c.eval_cap = (unsigned)eval_cap; c.defer_always = 0; c.ovf_count = nullptr; c.ovf_list = nullptr; c.out_rec = out_rec;
+        c.eval_cap = (unsigned)eval_cap; c.defer_always = 0; c.issue_cert = 1; c.ovf_count = nullptr; c.ovf_list = nullptr; c.out_rec = out_rec;
         c.mot = motion; c.stat = stat;
         hipError_t e = launch(search_grid_settled_kernel<4, 4>, dim3((unsigned)((n + kChunk - 1) / kChunk)), dim3(kWG), 0, s, c, pc, n,
                               cen_part, (unsigned)cen_chunks, cen_denom, order_switch, hint, fused->idx_out, fused->reject_d2,
@@ -1181,7 +1186,7 @@ hipError_t search_grid(hipStream_t s, Soa3 P, size_t n, double *pc, const Grid &
     auto kern = flight >= 8 ? search_grid_kernel<4, 8, 4> : flight >= 6 ? search_grid_kernel<4, 6, 4> : search_grid_kernel<4, 4, 5>;
     hipError_t e = launch(kern, dim3((unsigned)(xcd_map ? (wgs_rows + 7) / 8 * 8 : wgs_rows)), dim3(kWG), 0, s, P.x, P.y,
                           P.z, pc, n, g.d, g.start, g.rec, Qz.x, Qz.y, Qz.z, Qz.rec, (unsigned)m, idx_prev, P.rec, P.rec_stride, order,
-                          row_cap, (unsigned)eval_cap, sc ? sc->defer_always : 0, cnt, sc ? sc->list : nullptr, out_rec, motion,
+                          row_cap, (unsigned)eval_cap, sc ? sc->defer_always : 0, issue, cnt, sc ? sc->list : nullptr, out_rec, motion,
                           order_switch, stat, cen_part, (unsigned)cen_chunks, cen_denom, xcd_map, hint);
     if (e != hipSuccess || !sc) return e;
     size_t wgs = n < 512 ? n : 512;   // two per CU walk the queue; an empty queue (the usual case) costs the launch only

@@ -154,6 +154,7 @@ struct GridScratch {
     volatile uint32_t *host_mem = nullptr;  // host address: [0] the last overflow queue length, [1] 1 = the last search found the
                                             // registration settled (hints for the host's next launch, read without synchronisation)
     uint32_t *host_count = nullptr;         // device address of the same two words
+    int issue_cert = 1;                     // searches over row records leave motion certificates (the engine clears it with grid_cert=0)
     int fuse_cov = 1;                       // ICP_AMD_GRID_FUSE_COV=0: never the settled search that also forms the covariance sums
     int flight = 6;                         // candidate loads in flight per walking lane of search_grid_kernel (grid_flight=4|6|8)
     int parity = 0;
