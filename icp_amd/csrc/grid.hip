@@ -829,8 +829,10 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             wr.i = s_walk[w];
             if (grid_row_setup(ctx, wr, prec[wr.i], prec[stride + wr.i])) grid_row_walk<ROWS, FLIGHT>(ctx, wr);
         }
-        __threadfence();   // the walked rows' results have reached the L2 ...
-        __syncthreads();   // ... before the lanes that own those rows read them (past their L1, where the old line may sit).
+        // The walked rows' results were written by lanes of THIS workgroup: the barrier (a release / acquire pair at workgroup
+        // scope) orders them before the reads below.  No device-scope fence: on this part that is a write-back of the XCD's
+        // dirty L2 lines -- every row the launch has written so far -- per workgroup that walked (measured: HISTORY.md, round 3).
+        __syncthreads();
         // Nothing of the rows was kept in registers across the walk: a workgroup that had to walk reads its chunk again.
 #pragma unroll
         for (int k = 0; k < kCovW; ++k) acc[k] = 0.0;
@@ -840,10 +842,10 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             if (i < n) {
                 const double4 a = prec[i];
                 const double *b = (const double *)&prec[stride + i];
-                const double q0 = __hip_atomic_load(b + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const double q1 = __hip_atomic_load(b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const double q2 = __hip_atomic_load(b + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const uint32_t j = (uint32_t)__hip_atomic_load((const unsigned long long *)(b + 3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const double q0 = __hip_atomic_load(b + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const double q1 = __hip_atomic_load(b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const double q2 = __hip_atomic_load(b + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const uint32_t j = (uint32_t)__hip_atomic_load((const unsigned long long *)(b + 3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 cov_row_sums(ctx.m, reject_d2, a.x - ctx.pc[0], a.y - ctx.pc[1], a.z - ctx.pc[2], q0, q1, q2, j, idx_out + i, acc);
             }
         }

@@ -4,7 +4,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/${1:-sorted}
 mkdir -p $O
 cd $R
-export ICP_AMD_LIB=$R/icp_amd/libicp_amd_old.so
+export ICP_AMD_LIB=${PROBE_LIB:-$R/icp_amd/libicp_amd_old.so}
 run() { timeout -k 10 200 env "$@" python -u tools/sorted_source_probe.py >> $O/out.txt 2>&1 || { tail $O/out.txt; exit 1; }; }
 run PROBE_SORT=0
 run PROBE_SORT=1 ICP_AMD_GRID_ORDER=0
