@@ -466,13 +466,13 @@ def main():
         td.all_reduce(buf, op=td.ReduceOp.SUM)
         return [float(v) for v in buf.cpu()]
 
-    def run(search, steps, warmup, repeats=0, extras=False, block_times=False, kernel_timing=True, block=10):
+    def run(search, steps, warmup, repeats=0, extras=False, block_times=False, kernel_timing=True, block=10, sort_source=False):
         """`steps` timed iterations after `warmup` untimed ones.  Returns a dict: seconds (max over ranks), the search
         kernel's average launch ms (this rank's and every rank's), geometry, the last iteration's outputs, ...
         block_times (the grid legs, whose iteration is tens of microseconds): the iterations run ten at a time through
         ShardedIcp.steps -- on one rank the engine's own loop, one call across the C ABI per ten iterations."""
         runner = icpdist.ShardedIcp(P, Q, rank=rank, world=world, device=local_rank, search=search, kernel_timing=kernel_timing,
-                                    force_collective=force_pg)
+                                    force_collective=force_pg, sort_source=sort_source)
         runner.begin()
         first_ms = None
         for w in range(warmup):
@@ -580,6 +580,17 @@ def main():
                         "brute-force search, only the targets near each source point are evaluated; not counted in `value`. "
                         "`ms_per_step` is taken once the registration has settled (after `warmup_steps` iterations); "
                         "`first_steps` is the same measurement at the start of the registration"}
+        if world == 1 and not force_pg:
+            # the same first g_steps iterations with the source STORED in spatial order (icp_amd_options.sort_source; off by
+            # default because the reduction order, hence the last bits of Pc / cov, then follows the stored rows)
+            se = run("grid", g_steps, max(args.warmup, 3), block_times=True, kernel_timing=False, sort_source=True)
+            grid["sorted_source"] = {
+                "first_steps": {"ms_per_step": se["dt"] / g_steps * 1e3, "steps": g_steps, "ms_per_step_by_10": se["ms_per_step_by_10"]},
+                "rms_last_relative_difference": abs(se["last"]["rms"] - early["last"]["rms"]) / early["last"]["rms"],
+                # (after ~100 iterations on clouds that differ in the last bits: a row between two targets an ulp apart may differ)
+                "rows_whose_index_differs_from_unsorted": int((se["last"]["idx"] != early["last"]["idx"]).sum()),
+                "note": "icp_amd_options.sort_source = 1: rows sorted by a coarse cell at set_source, clouds and indices in and out "
+                        "in the caller's order; the settled iteration is unchanged (it streams either way)"}
 
     # BASELINE configs[4] beside the headline (one warm-up + three launches of 4096 x (1k x 1k) x 20 iterations, ~0.1 s of GPU
     # time; its CPU leg -- the oracle port on whole registrations, all cores -- a few seconds): `--no-batch` skips it

@@ -97,13 +97,14 @@ class Engine:
     """Persistent device-resident engine (icp_amd_create ... icp_amd_destroy)."""
 
     def __init__(self, device=0, stream=None, search="auto", q_splits=0, kernel_timing=False, rank=0, world=1,
-                 n_global=0, cov_gather=None, cen_gather=None, strict_order=False):
+                 n_global=0, cov_gather=None, cen_gather=None, strict_order=False, sort_source=False):
         o = Options()
         lib().icp_amd_default_options(C.byref(o))
         o.device, o.stream, o.search, o.q_splits = device, stream, SEARCH[search], q_splits
         o.kernel_timing, o.rank, o.world, o.n_global = int(kernel_timing), rank, world, n_global
         o.cov_gather, o.cen_gather = cov_gather, cen_gather
         o.strict_order = int(strict_order)
+        o.sort_source = int(sort_source)
         self._h = C.c_void_p()
         self.n = 0
         check(lib().icp_amd_create(C.byref(self._h), C.byref(o)))

@@ -18,7 +18,7 @@ class Trace(C.Structure):
 class Options(C.Structure):
     _fields_ = [("device", C.c_int), ("stream", C.c_void_p), ("search", C.c_int), ("q_splits", C.c_int),
                 ("kernel_timing", C.c_int), ("rank", C.c_int), ("world", C.c_int), ("n_global", C.c_size_t),
-                ("cov_gather", C.c_void_p), ("cen_gather", C.c_void_p), ("strict_order", C.c_int), ("reserved", C.c_int * 7)]
+                ("cov_gather", C.c_void_p), ("cen_gather", C.c_void_p), ("strict_order", C.c_int), ("sort_source", C.c_int), ("reserved", C.c_int * 6)]
 
 
 class IcpAmdError(RuntimeError):

@@ -151,8 +151,9 @@ struct icp_amd_engine {
     bool qrec_ok = false;       // qrec / qmax / f32_ok describe the current target (built with it, or by the first brute-force launch)
     Grid grid;                  // uniform grid over Qz (search variant GRID); built on first use per target
     bool grid_built = false;
-    uint32_t *order = nullptr;  // n_pad: source rows in spatial order (GRID), valid when order_ok
-    bool order_ok = false;
+    uint32_t *order = nullptr;  // n_pad: source rows in spatial order (GRID), valid when order_ok; or, when `sorted`, the row of the
+    bool order_ok = false;      // caller's cloud that each stored row is
+    bool sorted = false;        // the source is STORED in spatial order (options.sort_source): stored row k = caller's row order[k]
     GridScratch gscratch;       // queue of the points the grid search hands to its overflow kernel
     double4 *p_rec = nullptr;   // 2 * n_pad: per source row A = {x,y,z,-} in the first half, B = {matched target, idx | certificate} in the second (GRID)
     bool soa_stale = false;     // the running cloud lives in the records' A half (apply updated only that); P.x/y/z are behind
@@ -319,11 +320,20 @@ static int prepare_grid_source(icp_amd_engine *e);
 static const size_t kMaxRows = 0x7FFFFC00u;  // indices are 32-bit; padded sizes must fit too
 static const size_t kGridOrderMinRows = (size_t)1 << 18;   // source rows from which the grid search takes them in a spatial order
 static const size_t kStrictMaxSource = 4096, kStrictMaxTarget = (size_t)1 << 20;   // one lane sums these sequentially
+static const size_t kSortMinRows = (size_t)1 << 18;   // options.sort_source: sources from this many rows on are stored in spatial order (below,
+                                                       // computing the order costs a short registration more than it saves)
 static bool strict_requested(const icp_amd_options &opt)
 {
     if (opt.strict_order) return true;
     const char *v = getenv("ICP_AMD_STRICT_ORDER");
     if (!v) v = getenv("ICP_STRICT_ORDER");   // the name SURVEY.md 7.3 uses
+    return v && atoi(v) != 0;
+}
+
+static bool sort_requested(const icp_amd_options &opt)
+{
+    if (opt.sort_source) return true;
+    const char *v = getenv("ICP_AMD_SORT_SOURCE");
     return v && atoi(v) != 0;
 }
 
@@ -550,7 +560,7 @@ static int prepare_grid_source(icp_amd_engine *e)
 {
     const size_t n = e->n, n_pad = e->n_pad;
     RCCHK(sync_soa(e));   // the records are rebuilt from the SoA arrays below
-    e->order_ok = false;
+    e->order_ok = false;    // (a source stored in spatial order needs none: e->order then maps stored rows to the caller's)
     e->P.rec = nullptr;
     e->P.rec_stride = 0;
     if (n && wants_grid(e)) {
@@ -567,7 +577,7 @@ static int prepare_grid_source(icp_amd_engine *e)
         // 0.91 with; 300k: 1.53 / 1.43) and computing it is 0.1-0.15 ms of set_source -- a sixth of a whole registration of
         // the cow pair.  grid_order=1 / 0 forces it on / off.
         const int order_knob = knob_int("grid_order", -1);
-        if (order_knob > 0 || (order_knob < 0 && n >= kGridOrderMinRows)) {
+        if (!e->sorted && (order_knob > 0 || (order_knob < 0 && n >= kGridOrderMinRows))) {
             if (!e->order) HIPCHK(dmalloc(&e->order, n_pad * sizeof(uint32_t)));
             HIPCHK(grid_order(e->stream, e->P, n, e->order));
             e->order_ok = true;
@@ -633,6 +643,20 @@ extern "C" int icp_amd_set_source(icp_amd_engine *e, const double *P, size_t n)
     }
     HIPCHK(aos_to_soa(e->stream, e->stage, n, n_pad, nullptr, 0.0, e->P));
     e->soa_stale = false;
+    // options.sort_source: the rows sorted by a coarse cell of their own bounding volume, ascending index inside a cell (a
+    // function of the cloud alone), and the cloud stored in that order from here on.  One GPU, not under strict order (whose
+    // sums follow the caller's rows); a cloud with a cell too full to order (thousands of coincident rows) stays as it is.
+    e->sorted = false;
+    if (n >= (size_t)knob_int("sort_min", (int)kSortMinRows) && world == 1 && sort_requested(e->opt) &&
+        !(e->strict && n <= kStrictMaxSource)) {
+        if (!e->order) HIPCHK(dmalloc(&e->order, n_pad * sizeof(uint32_t)));
+        bool stable = false;
+        HIPCHK(grid_order(e->stream, e->P, n, e->order, &stable));
+        if (stable) {
+            HIPCHK(aos_gather_to_soa(e->stream, e->stage, e->order, n, n_pad, 0.0, e->P));
+            e->sorted = true;
+        }
+    }
     RCCHK(prepare_grid_source(e));
     e->bf_left = e->bf_backoff = 0;
     HIPCHK(hipStreamSynchronize(e->stream));  // P may be reused by the caller after return
@@ -922,7 +946,8 @@ extern "C" int icp_amd_get_source(icp_amd_engine *e, double *P_out)
     if (e->n) {
         RCCHK(ensure_stage(e, e->n));
         RCCHK(sync_soa(e));
-        HIPCHK(soa_to_aos(e->stream, e->P, e->n, e->stage));
+        if (e->sorted) HIPCHK(soa_scatter_to_aos(e->stream, e->P, e->order, e->n, e->stage));   // back into the caller's row order
+        else HIPCHK(soa_to_aos(e->stream, e->P, e->n, e->stage));
     }
     RCCHK(copy_out(e, P_out, e->stage, e->n * 3 * sizeof(double)));   // synchronises the stream
     return ICP_AMD_OK;
@@ -935,7 +960,16 @@ extern "C" int icp_amd_get_last(icp_amd_engine *e, double *Pc, int32_t *idx, dou
     HIPCHK(set_device(e->opt.device));
     double rec[kSolveW];
     HIPCHK(hipMemcpyAsync(rec, e->rec, sizeof rec, hipMemcpyDeviceToHost, e->stream));
-    RCCHK(copy_out(e, idx, e->idx, idx ? e->n * sizeof(uint32_t) : 0));   // synchronises the stream
+    if (idx && e->n && e->sorted) {   // the indices of the stored rows, back into the caller's row order
+        uint32_t *tmp = nullptr;
+        HIPCHK(dmalloc(&tmp, e->n * sizeof(uint32_t)));
+        hipError_t er = scatter_u32(e->stream, e->idx, e->order, e->n, tmp);
+        int rc = er == hipSuccess ? copy_out(e, idx, tmp, e->n * sizeof(uint32_t)) : ICP_AMD_OK;
+        free_dev(e, tmp);
+        HIPCHK(er);
+        RCCHK(rc);
+    } else
+        RCCHK(copy_out(e, idx, e->idx, idx ? e->n * sizeof(uint32_t) : 0));   // synchronises the stream
     if (cov) memcpy(cov, rec, 9 * sizeof(double));
     if (S) memcpy(S, rec + 9, 3 * sizeof(double));
     if (R) memcpy(R, rec + 12, 9 * sizeof(double));

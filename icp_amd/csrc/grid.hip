@@ -1115,18 +1115,53 @@ __global__ __launch_bounds__(kWG) void iota_kernel(uint32_t *out, size_t n)
 // order[0, n) = the source rows sorted by the cell of a coarse grid over the source cloud itself (about two waves of
 // points per cell, cells in x-fastest order).  Rigid motions keep neighbours together, so the order computed once
 // stays good for every iteration.  Rows with non-finite coordinates anywhere: identity order.
-hipError_t grid_order(hipStream_t s, Soa3 P, size_t n, uint32_t *order)
+// One wave per cell: the cell's rows into ascending index (each finds its rank by counting the smaller ones).  Cells of more
+// than kOrderRunMax rows are left as they are and reported.
+constexpr unsigned kOrderRunMax = 4096;
+__global__ __launch_bounds__(64) void grid_order_stable_kernel(const uint32_t *__restrict__ start, uint32_t *__restrict__ perm,
+                                                               uint32_t *__restrict__ too_long)
 {
+    __shared__ uint32_t v[kOrderRunMax];
+    const uint32_t s0 = start[blockIdx.x], k = start[blockIdx.x + 1] - s0;
+    if (k < 2) return;
+    if (k > kOrderRunMax) {
+        if (threadIdx.x == 0) *too_long = 1u;   // (every writer stores the same value)
+        return;
+    }
+    for (uint32_t i = threadIdx.x; i < k; i += 64) v[i] = perm[s0 + i];
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < k; i += 64) {
+        const uint32_t mine = v[i];
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < k; ++j) rank += v[j] < mine ? 1u : 0u;
+        perm[s0 + rank] = mine;
+    }
+}
+
+hipError_t grid_order(hipStream_t s, Soa3 P, size_t n, uint32_t *order, bool *stable)
+{
+    if (stable) *stable = false;
     if (n == 0) return hipSuccess;
     Grid g;
     hipError_t e = grid_sort(s, P, n, 128.0, false, false, &g);
     if (e != hipSuccess) return e;
+    uint32_t *flag = nullptr;
+    uint32_t host_flag = 1;
     if (g.ok) {
-        e = hipMemcpyAsync(order, g.perm, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, s);
+        if (stable && g.cells <= 0x7FFFFFFFu) {
+            e = dmalloc(&flag, sizeof(uint32_t));
+            if (e == hipSuccess) e = hipMemsetAsync(flag, 0, sizeof(uint32_t), s);
+            if (e == hipSuccess) e = launch(grid_order_stable_kernel, dim3((unsigned)g.cells), dim3(64), 0, s, g.start, g.perm, flag);
+            if (e == hipSuccess) e = hipMemcpyAsync(&host_flag, flag, sizeof host_flag, hipMemcpyDeviceToHost, s);
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(order, g.perm, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, s);
     } else {
         e = launch(iota_kernel, dim3((unsigned)((n + kWG - 1) / kWG)), dim3(kWG), 0, s, order, n);
+        host_flag = 0;   // the identity is as stable as it gets
     }
     if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e == hipSuccess && stable) *stable = host_flag == 0;
+    if (flag) (void)dfree_on(flag, s);
     grid_free(&g);
     return e;
 }

@@ -85,6 +85,11 @@ hipError_t finalize_centroid(hipStream_t s, const double *partial, size_t count,
 // AoS -> SoA, padded rows [n, n_pad) set to `pad`.  If c3 != nullptr subtracts c3[k] (the centring of Q).
 hipError_t aos_to_soa(hipStream_t s, const double *aos, size_t n, size_t n_pad, const double *c3, double pad, Soa3 out);
 hipError_t soa_to_aos(hipStream_t s, Soa3 in, size_t n, double *aos);
+// the same through a row permutation (a source stored in spatial order): out row k = aos row perm[k]; aos row perm[k] = in row k;
+// dst[perm[k]] = src[k]
+hipError_t aos_gather_to_soa(hipStream_t s, const double *aos, const uint32_t *perm, size_t n, size_t n_pad, double pad, Soa3 out);
+hipError_t soa_scatter_to_aos(hipStream_t s, Soa3 in, const uint32_t *perm, size_t n, double *aos);
+hipError_t scatter_u32(hipStream_t s, const uint32_t *src, const uint32_t *perm, size_t n, uint32_t *dst);
 
 // Split geometry of both search kernels: targets [0, search_scan_rows(m)) in q_splits pieces of
 // search_rows_per_split(m, q_splits) targets each (trailing pieces may be empty; their records read (inf, ~0) or the seed).
@@ -204,7 +209,10 @@ hipError_t search_grid(hipStream_t s, Soa3 P, size_t n, double *pc, const Grid &
 hipError_t build_source_rec(hipStream_t s, Soa3 P, size_t rows);
 // x, y, z [i] = A[i] for i < rows: the SoA arrays caught up with the running cloud of the records
 hipError_t source_rec_to_soa(hipStream_t s, Soa3 P, size_t rows);
-hipError_t grid_order(hipStream_t s, Soa3 P, size_t n, uint32_t *order);
+// stable (optional): the rows of a cell in ascending index, so that the order is a function of the cloud alone (the counting
+// sort leaves them in the order its atomics were served); *stable = false when a cell holds too many rows for that (the order
+// is then still a valid permutation).
+hipError_t grid_order(hipStream_t s, Soa3 P, size_t n, uint32_t *order, bool *stable = nullptr);
 
 // The reference's own reduction order (icp_amd_options::strict_order), one lane per output.  Source of the rows: aos (n x 3
 // row-major) if given, else the records' A half if P.rec is set, else the SoA arrays.

@@ -92,6 +92,37 @@ __global__ __launch_bounds__(kWG) void soa_to_aos_kernel(const double *__restric
     aos[i * 3 + 2] = z[i];
 }
 
+// A source stored in spatial order (engine option sort_source): row k of the engine's arrays is row perm[k] of the caller's.
+// The cloud goes in through a gather and comes out through a scatter; so do the correspondence indices.
+__global__ __launch_bounds__(kWG) void aos_gather_to_soa_kernel(const double *__restrict__ aos, const uint32_t *__restrict__ perm, size_t n,
+                                                                size_t n_pad, double pad, double *__restrict__ x, double *__restrict__ y,
+                                                                double *__restrict__ z)
+{
+    const size_t k = (size_t)blockIdx.x * kWG + threadIdx.x;
+    if (k >= n_pad) return;
+    const size_t i = k < n ? perm[k] : 0;
+    x[k] = k < n ? aos[i * 3 + 0] : pad;
+    y[k] = k < n ? aos[i * 3 + 1] : pad;
+    z[k] = k < n ? aos[i * 3 + 2] : pad;
+}
+__global__ __launch_bounds__(kWG) void soa_scatter_to_aos_kernel(const double *__restrict__ x, const double *__restrict__ y,
+                                                                 const double *__restrict__ z, const uint32_t *__restrict__ perm, size_t n,
+                                                                 double *__restrict__ aos)
+{
+    const size_t k = (size_t)blockIdx.x * kWG + threadIdx.x;
+    if (k >= n) return;
+    const size_t i = perm[k];
+    aos[i * 3 + 0] = x[k];
+    aos[i * 3 + 1] = y[k];
+    aos[i * 3 + 2] = z[k];
+}
+__global__ __launch_bounds__(kWG) void scatter_u32_kernel(const uint32_t *__restrict__ src, const uint32_t *__restrict__ perm, size_t n,
+                                                          uint32_t *__restrict__ dst)
+{
+    const size_t k = (size_t)blockIdx.x * kWG + threadIdx.x;
+    if (k < n) dst[perm[k]] = src[k];
+}
+
 // ------------------------------------------------------------------------------------------------
 // correspondence search
 // ------------------------------------------------------------------------------------------------
@@ -1240,6 +1271,21 @@ hipError_t soa_to_aos(hipStream_t s, Soa3 in, size_t n, double *aos)
 {
     if (n == 0) return hipSuccess;
     return launch(soa_to_aos_kernel, dim3(blocks_for(n, kWG)), dim3(kWG), 0, s, in.x, in.y, in.z, n, aos);
+}
+hipError_t aos_gather_to_soa(hipStream_t s, const double *aos, const uint32_t *perm, size_t n, size_t n_pad, double pad, Soa3 out)
+{
+    if (n_pad == 0) return hipSuccess;
+    return launch(aos_gather_to_soa_kernel, dim3(blocks_for(n_pad, kWG)), dim3(kWG), 0, s, aos, perm, n, n_pad, pad, out.x, out.y, out.z);
+}
+hipError_t soa_scatter_to_aos(hipStream_t s, Soa3 in, const uint32_t *perm, size_t n, double *aos)
+{
+    if (n == 0) return hipSuccess;
+    return launch(soa_scatter_to_aos_kernel, dim3(blocks_for(n, kWG)), dim3(kWG), 0, s, in.x, in.y, in.z, perm, n, aos);
+}
+hipError_t scatter_u32(hipStream_t s, const uint32_t *src, const uint32_t *perm, size_t n, uint32_t *dst)
+{
+    if (n == 0) return hipSuccess;
+    return launch(scatter_u32_kernel, dim3(blocks_for(n, kWG)), dim3(kWG), 0, s, src, perm, n, dst);
 }
 
 // Split geometry shared by both search kernels: the scanned range is m rounded up to kSplitGran targets (pads inside

@@ -45,14 +45,15 @@ def exchange_partials(buf, width, rank, world, group=None, force=False):
 class ShardedIcp:
     """Drives one engine per process.  world == 1 needs no torch at all."""
 
-    def __init__(self, P, Q, rank=0, world=1, device=0, search="auto", kernel_timing=False, group=None, force_collective=False):
+    def __init__(self, P, Q, rank=0, world=1, device=0, search="auto", kernel_timing=False, group=None, force_collective=False,
+                 sort_source=False):
         self.rank, self.world, self.group = rank, world, group
         self.collective = world > 1 or force_collective   # exchange buffers + the two all-gathers per iteration
         n_global = len(P)
         lo, hi = shard_bounds(n_global, rank, world)
         self.lo, self.hi, self.n_local, self.n_global = lo, hi, hi - lo, n_global
         self.cov = self.cen = self.stream = None
-        kw = dict(device=device, search=search, kernel_timing=kernel_timing)
+        kw = dict(device=device, search=search, kernel_timing=kernel_timing, sort_source=sort_source)   # (sort_source: one rank only)
         if self.collective:
             import torch
             cpr = chunks_per_rank(n_global, world)

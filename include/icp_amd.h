@@ -90,7 +90,17 @@ typedef struct icp_amd_options {
      * source rows (1 Mi target rows for the target's centroid) on one GPU; larger clouds, sharded runs and the rejection hook
      * keep the trees.  Indices are identical either way.  SURVEY.md 7.3-3c. */
     int    strict_order;
-    int    reserved[7];
+    /* 1 (or ICP_AMD_SORT_SOURCE=1 in the environment): the engine keeps a large source cloud (2^18 rows or more, one GPU, not
+     * strict order) in a spatial order of its own -- rows sorted by a coarse cell, ascending index inside a cell: a function
+     * of the cloud alone -- instead of reaching the caller's rows through a permutation.  The grid search's row accesses are
+     * then contiguous: 10 % off a whole 1M x 1M registration.  Clouds and indices go in and come out in the CALLER's order
+     * (gather on the way in, scatter on the way out).  What changes: the reduction leaves are 1024-row chunks of the STORED
+     * order, so Pc and cov are summed in another order than without the option and differ in the last bits (same bar against
+     * the reference, indices exact for the cloud at hand; still the same bits from run to run and across search variants).
+     * Off by default: results are then also independent of the GPU count, which a per-rank sort cannot give.  No counterpart
+     * in the reference. */
+    int    sort_source;
+    int    reserved[6];
 } icp_amd_options;
 
 const char *icp_amd_last_error(void);
