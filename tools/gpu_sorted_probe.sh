@@ -1,4 +1,5 @@
 #!/bin/bash
+# tools/sorted_source_probe.py under its variants (unsorted baseline; source sorted on the host with the engine's own permutation on / off; the fused storage-order kernel forced), old library by default
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/${1:-sorted}
