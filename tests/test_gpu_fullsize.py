@@ -118,12 +118,16 @@ def test_full_size_rows_kernel_level_against_the_reference(name, groups, monkeyp
 
 
 @pytest.mark.parametrize("name,search", [("syn100k_rows", "auto"), ("syn100k_rows", "f32"), ("syn100k_rows", "grid"),
-                                         ("syn1m_rows", "f32"), ("syn1m_rows", "auto")])
+                                         ("syn1m_rows", "f32"), ("syn1m_rows", "auto"), ("syn1m_rows", "auto+sort"),
+                                         ("syn1m_rows", "f32+sort")])
 def test_full_size_loop_agrees_with_the_reference_on_sampled_rows(name, search):
     """configs[2] for its 30 iterations (checked at 1, 15, 30) and configs[3] (1 and 3: un-seeded and seeded launches of the
-    kernel the benchmark times) through the engine."""
+    kernel the benchmark times) through the engine; configs[3] also with the source stored in spatial order
+    (icp_amd_options.sort_source: the rows and their indices still come back in the caller's order)."""
     g, P, Q, rows, iters_at = _rows_fixture(name)
-    e = icp_amd.Engine(search=search)
+    sort = search.endswith("+sort")
+    search = search.split("+")[0]
+    e = icp_amd.Engine(search=search, sort_source=sort)
     e.set_target(Q)
     e.set_source(P)
     assert relerr(e.target_centroid(), g["Qc"]) < 1e-13
