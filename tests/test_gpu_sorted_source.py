@@ -116,3 +116,38 @@ def test_sorted_storage_declines_where_it_cannot_or_need_not(monkeypatch):
     (c,), Pc_ = run(same, Q, 2, sort=True)
     (d,), Pd = run(same, Q, 2, sort=False)
     assert np.array_equal(c["idx"], d["idx"]) and np.array_equal(Pc_, Pd)
+
+
+def test_sorted_storage_follows_target_and_source_replacement(monkeypatch):
+    """A target replaced under a sorted source (the row records are rebuilt from the stored order), then a source of another
+    size (a new order): after each change the next search's indices are the oracle's for the cloud at hand, in the
+    caller's row order -- also when AUTO answers by brute force (a target below the grid's floor)."""
+    monkeypatch.setenv("ICP_AMD_SORT_MIN", "0")
+
+    def check(e, Q):
+        cloud = e.get_source()
+        e.iterate(1)
+        got = e.get_last()
+        want = orc.correspondences(cloud - got["Pc"], Q - orc.mean0(Q), nthreads=8)
+        assert np.array_equal(got["idx"], want)
+
+    P1, Q1 = synth.make_pair(30000, 28000, seed=81)
+    P2, Q2 = synth.make_pair(17000, 40000, seed=82, angle=0.3)
+    _, Q3 = synth.make_pair(500, 900, seed=83)           # fewer than 1024 targets: AUTO searches by brute force
+    e = icp_amd.Engine(sort_source=True)
+    e.set_target(Q1)
+    e.set_source(P1)
+    e.iterate(3)
+    check(e, Q1)
+    e.set_target(Q2)
+    check(e, Q2)
+    e.iterate(2)
+    check(e, Q2)
+    e.set_source(P2)
+    check(e, Q2)
+    e.iterate(2)
+    check(e, Q2)
+    e.set_target(Q3)
+    check(e, Q3)
+    assert e.search_geometry()["variant"] != "grid"
+    e.close()
