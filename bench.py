@@ -83,15 +83,15 @@ def roofline(variant, n_local, M, avg_ms, launches):
     peak = PEAK_FP32_VALU if f32 else PEAK_FP64_VALU_NOFMA
     mix = {"f32": "fast path = fp32 pre-filter, 3 v_fma_f32 (or 1.5 v_pk_fma_f32) + 0.5 v_min3_f32 per pair; every candidate "
                   "re-evaluated in un-fused fp64 (indices bit-identical to the fp64 variants)",
-           "fma": "fast path = 7.08 fp64 VALU instructions per pair (3 add, 1 mul, 2 fma, 1 min); candidates re-evaluated un-fused",
-           "exact": "fast path = 9.08 fp64 VALU instructions per pair (the oracle's 8 un-fused ops + 1 min)"}.get(variant, variant)
+           "fma": "fast path = 6.58 VALU instructions per pair (3 add, 1 mul, 2 fma in fp64 + half a v_min3_u32 on the high words); candidates re-evaluated un-fused",
+           "exact": "fast path = 8.58 VALU instructions per pair (the oracle's 8 un-fused fp64 ops + half a v_min3_u32 on the high words of two d^2)"}.get(variant, variant)
     return {"bound": "valu_fp32" if f32 else "valu_fp64", "kernel": "search_f32_kernel" if f32 else "search_kernel",
             "achieved": ach / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s", "frac": ach / peak,
             "flops_per_pair": FLOPS_PER_PAIR, "pairs_per_launch": float(n_local) * float(M), "avg_launch_ms": avg_ms,
             "launches": launches, "traffic": None, "variant": variant, "instruction_mix": mix,
             "note": ("fp32 vector peak 157.3 TFLOP/s" if f32 else
                      "un-fused fp64 VALU peak 39.3 TFLOP/s = one flop per op (FMA-counted datasheet peak: 78.6); the FMA "
-                     "variant issues 7.08 instructions for the 8 algorithmic flops, so its frac can pass 1")}
+                     "variant issues 6.58 instructions for the 8 algorithmic flops, so its frac can pass 1")}
 
 
 # what the box's memory system delivers for plain streams at the grid iteration's sizes (tools/ubench_stream.hip at 1M rows,

@@ -142,7 +142,8 @@ __global__ __launch_bounds__(kWG) void scatter_u32_kernel(const uint32_t *__rest
 template <int PPL>
 struct LaneSearch {
     double ax[PPL], ay[PPL], az[PPL];  // centred source points: P = P_copy - P_center (src/cpu/icp.cpp:208)
-    double m_[PPL];                    // running minimum in filter space, starts each block at thr
+    uint32_t mh[PPL];                  // running minimum of the HIGH WORDS of the filter values, starts each block at thr_hi + 1
+    uint32_t thr_hi[PPL];              // high word of thr
     double thr[PPL];                   // filter-space image of bd
     double bd[PPL], bk[PPL];
     uint32_t bj[PPL];
@@ -157,37 +158,61 @@ __device__ __forceinline__ double filter_threshold(double bd)
     return (MODE == kFma) ? __builtin_fma(bd, 1.0 + 0x1p-49, 1e-300) : bd;
 }
 
+// The fast path tracks no fp64 minimum at all.  A squared distance is a non-negative double, and non-negative doubles order
+// like their bit patterns: a target can be below the threshold only if the HIGH 32 bits of its d^2 (sign, exponent, twenty
+// mantissa bits -- the upper register of the pair, no instruction to get at it) are <= those of the threshold.  One
+// v_min3_u32 folds the high words of TWO targets into the running minimum: half an instruction per pair where v_min_f64
+// took one (9.08 -> 8.58 per pair in EXACT, 7.08 -> 6.58 in FMA).  A block is re-scanned exactly when its minimum high word
+// is <= the threshold's: every target that could beat or tie the threshold is in such a block, and a block that only shares
+// the threshold's high word (a 2^-20 band) costs a re-scan that changes nothing.  NaN and inf have high words above every
+// finite threshold, like the fmin they replace.
+__device__ __forceinline__ uint32_t umin3(uint32_t a, uint32_t b, uint32_t c)
+{
+    uint32_t r;   // (written out: left to itself the compiler re-associates the minima into trees of v_min_u32, 0.7 per pair)
+    asm("v_min3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ void set_threshold(double thr, double &out_thr, uint32_t &out_hi, uint32_t &out_mh)
+{
+    out_thr = thr;
+    out_hi = (uint32_t)__double2hiint(thr);
+    out_mh = out_hi + 1u;   // "nothing at or below the threshold's high word yet" (thr >= 0 or +inf: no wrap)
+}
+
 // Scan `count` (multiple of CB) targets held in LDS as SoA; jbase = global index of target 0 of the tile.
 template <int PPL, int MODE, int CB>
 __device__ __forceinline__ void scan_tile(LaneSearch<PPL> &L, const double *sx, const double *sy, const double *sz, int count,
                                           unsigned jbase)
 {
     for (int j0 = 0; j0 < count; j0 += CB) {
+        static_assert(CB % 2 == 0, "targets are taken two at a time");
 #pragma unroll
-        for (int u = 0; u < CB; ++u) {
-            const double tx = sx[j0 + u], ty = sy[j0 + u], tz = sz[j0 + u];
+        for (int u = 0; u < CB; u += 2) {
+            const double tx0 = sx[j0 + u], ty0 = sy[j0 + u], tz0 = sz[j0 + u];
+            const double tx1 = sx[j0 + u + 1], ty1 = sy[j0 + u + 1], tz1 = sz[j0 + u + 1];
 #pragma unroll
             for (int s = 0; s < PPL; ++s) {
-                const double d = (MODE == kFma) ? d2_fused(L.ax[s], L.ay[s], L.az[s], tx, ty, tz)
-                                                : d2_exact(L.ax[s], L.ay[s], L.az[s], tx, ty, tz);
-                L.m_[s] = __builtin_fmin(L.m_[s], d);
+                const double d0 = (MODE == kFma) ? d2_fused(L.ax[s], L.ay[s], L.az[s], tx0, ty0, tz0)
+                                                 : d2_exact(L.ax[s], L.ay[s], L.az[s], tx0, ty0, tz0);
+                const double d1 = (MODE == kFma) ? d2_fused(L.ax[s], L.ay[s], L.az[s], tx1, ty1, tz1)
+                                                 : d2_exact(L.ax[s], L.ay[s], L.az[s], tx1, ty1, tz1);
+                L.mh[s] = umin3(L.mh[s], (uint32_t)__double2hiint(d0), (uint32_t)__double2hiint(d1));
             }
         }
         const unsigned blk = (jbase + (unsigned)j0) / CB;
         bool ev = false;
 #pragma unroll
         for (int s = 0; s < PPL; ++s) {
-            if (blk == L.sblk[s]) L.m_[s] = L.thr[s];   // the seed's own block was evaluated exactly by seed_init
-            ev |= (L.m_[s] < L.thr[s]);
+            if (blk == L.sblk[s]) L.mh[s] = L.thr_hi[s] + 1u;   // the seed's own block was evaluated exactly by seed_init
+            ev |= (L.mh[s] <= L.thr_hi[s]);
         }
         if (ev) {
 #pragma unroll
             for (int s = 0; s < PPL; ++s) {
-                if (L.m_[s] < L.thr[s]) {
+                if (L.mh[s] <= L.thr_hi[s]) {
                     double dbest;
                     rescan_block<CB>(L.ax[s], L.ay[s], L.az[s], sx, sy, sz, j0, jbase + (unsigned)j0, L.bd[s], L.bk[s], L.bj[s], dbest);
-                    L.thr[s] = filter_threshold<MODE>(L.bd[s]);
-                    L.m_[s] = __builtin_fmin(L.thr[s], INFINITY);
+                    set_threshold(filter_threshold<MODE>(L.bd[s]), L.thr[s], L.thr_hi[s], L.mh[s]);
                 }
             }
         }
@@ -218,8 +243,7 @@ __global__ __launch_bounds__(kWG) void search_kernel(const double *__restrict__ 
         L.az[s] = pz[base + s * kWG] - c2;
         const uint32_t js = idx_prev ? idx_prev[base + s * kWG] : 0xFFFFFFFFu;
         L.bd[s] = seed_init<CB>(L.ax[s], L.ay[s], L.az[s], qx, qy, qz, js, m, q0, q1, L.bk[s], L.bj[s], L.sblk[s]);
-        L.thr[s] = filter_threshold<MODE>(L.bd[s]);
-        L.m_[s] = __builtin_fmin(L.thr[s], INFINITY);
+        set_threshold(filter_threshold<MODE>(L.bd[s]), L.thr[s], L.thr_hi[s], L.mh[s]);
     }
 
     for (unsigned t0 = q0; t0 < q1; t0 += kTileQ) {
