@@ -175,8 +175,10 @@ __device__ __forceinline__ uint32_t umin3(uint32_t a, uint32_t b, uint32_t c)
 __device__ __forceinline__ void set_threshold(double thr, double &out_thr, uint32_t &out_hi, uint32_t &out_mh)
 {
     out_thr = thr;
-    out_hi = (uint32_t)__double2hiint(thr);
-    out_mh = out_hi + 1u;   // "nothing at or below the threshold's high word yet" (thr >= 0 or +inf: no wrap)
+    // (no threshold yet, thr = +inf: every FINITE d^2 is below it and an infinite one -- a row or a target out of range -- is
+    // not, so the word to compare with is the largest finite one; the exact high word would re-scan every block of such a row)
+    out_hi = thr < INFINITY ? (uint32_t)__double2hiint(thr) : 0x7FEFFFFFu;
+    out_mh = out_hi + 1u;   // "nothing at or below the threshold's high word yet" (thr >= 0: no wrap)
 }
 
 // Scan `count` (multiple of CB) targets held in LDS as SoA; jbase = global index of target 0 of the tile.
