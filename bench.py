@@ -264,6 +264,11 @@ def measure_batch(args, rank, world, local_rank, steps, warmup, with_cpu):
         return None
     pairs = float(args.batch) * n * n * args.batch_iters
     ach = FLOPS_PER_PAIR * float(hi - lo) * n * n * args.batch_iters / (kms / steps * 1e-3)
+    issue_frac = None
+    if os.environ.get("ICP_AMD_SEARCH", "") not in ("exact", "fma"):   # the default forms; the difference forms have other counts
+        seeded = os.environ.get("ICP_AMD_BATCH_SEEDED", "1") != "0"
+        instr = float(hi - lo) * n * n * (7.0 + (3.5 if seeded else 7.0) * (args.batch_iters - 1))
+        issue_frac = instr / (kms / steps * 1e-3) / (CUS * 4 * 16 * CLOCK_HZ)
     cpu = None
     if with_cpu:
         # the oracle port (the reference's loop, oracle/icp_oracle.c) on whole registrations of the same batch: each
@@ -300,8 +305,13 @@ def measure_batch(args, rank, world, local_rank, steps, warmup, with_cpu):
                      # indices; everything else stays in LDS / registers.  Algorithmic bytes, not a counter reading.
                      "algorithmic_bytes": float(hi - lo) * (n * 24 * 2 + n * 24 + n * 4 + 28 * 8),
                      "traffic": batch_traffic[0], "traffic_source_commit": batch_traffic[2], "traffic_note": batch_traffic[1],
-                     "note": "8 un-fused fp64 flops per pair against the un-fused fp64 VALU peak; the kernel's default form "
-                             "issues 7 fp64 instructions per pair (3 FMA), so frac can approach 8/7"},
+                     "issue_frac": issue_frac,
+                     "instruction_mix": "first iteration: 7 VALU instructions per pair (3 fp64 FMA, index embedded in the mantissa, "
+                                        "best and runner-up); from the second on, seeded by the previous match: 3.5 (3 fp64 FMA + half "
+                                        "a v_min3_u32 on the high words), candidate blocks re-scanned in the oracle's arithmetic",
+                     "note": "8 un-fused fp64 flops per pair against the un-fused fp64 VALU peak; the default form issues 3.5 "
+                             "instructions per pair from the second iteration on, so frac passes 1.  `issue_frac` = the fast "
+                             "path's instruction count of this launch / its duration / the VALU issue rate at the nominal 2.4 GHz"},
         "cpu_baseline": cpu,
         "gpu_over_cpu": (pairs * steps / dt) / cpu["value"] if cpu else None,
         "reference_semantics": "no counterpart: the reference's -batch flag strip-mines ONE registration 16 source rows at a "

@@ -35,7 +35,7 @@ constexpr int kTileQ   = 1024;   // target points per LDS tile; Q arrays are pad
 constexpr int kCovW    = 12;     // doubles per cov partial: 9 cov sums, sum d^2, 2 spare
 constexpr int kCenW    = 3;      // doubles per centroid partial
 
-enum SearchVariant { kExact = 1, kFma = 2, kF32 = 3, kGrid = 4, kExpanded = 5 /* batch mode only */ };
+enum SearchVariant { kExact = 1, kFma = 2, kF32 = 3, kGrid = 4, kExpanded = 5 /* batch mode only */, kSeeded = 6 /* batch mode: kExpanded, seeded from the second iteration on */ };
 constexpr size_t kPadRows = 2048;  // clouds are padded to this many rows (covers every kernel's tile)
 constexpr size_t kSplitGran = 128; // target splits are whole multiples of this many targets (>= every kernel's event-check block)
 

@@ -980,6 +980,143 @@ __device__ __forceinline__ void scan_small_expanded(const double (&ax)[PPL], con
     }
 }
 
+// --- seeded form (batch default from the second iteration on): the previous iteration's match is a candidate, so a row
+// knows a bound bd on its answer's d^2 before it looks at a single target, and the engine's event scheme (search_kernel) works
+// here too -- no index is embedded and no runner-up is tracked.  The fast path is the three FMAs of the expanded form on
+// records whose fourth word is |q|^2 + C, and half a v_min3_u32 on the HIGH words of two such values: 3.5 instructions per
+// pair instead of 7.  C (a power of two >= 4 max(|a|^2, |q|^2), fixed when the second iteration starts) keeps every value
+// positive, so that they order like their high words:
+//     f_j = fl(|q_j|^2 + C - 2 a.q_j),   F_j = d^2_j - |a|^2 + C exactly,   |f_j - F_j| <= E = 2^-52 (11 |a| qmax + 5 qmax^2 + 8 C)
+// (the expanded form's bound with the roundings of the offset: the record's word, three FMAs on values up to ~2C, and the
+// threshold's own arithmetic).  A target that can beat or tie the row's best has an oracle d^2 <= bd, hence
+//     f_j <= bd (1 + 2^-50) - |a|^2 (1 - 2^-50) + C + E =: thr,
+// and a block of kBatchCB targets whose smallest high word is <= thr's is re-scanned in the oracle's arithmetic, in target
+// order, with the engine's own (key, index) rules (rescan_block): the indices are the oracle's.  f_j >= C - |a|^2 - E > 0 is
+// checked per row (C > 2 |a|^2 + 4 E); a row that fails it -- or a registration whose range defeats the bound -- is scanned
+// exactly, as the expanded form does.  While the clouds still move a tenth of the rows re-scan a block or two per iteration.
+constexpr int kBatchCB = 8;
+
+// rescan_block (search_common.h) on the records: q = -X/2 exactly.  The empty asm ties the loads to this call: without it the
+// branch-free first pass over the block -- whose records the caller has just loaded -- was hoisted in front of the event
+// test and ran for every block, doubling the fast path.  (As a real call it cost 0.3 ms of 13.5 and 760 MB of register
+// spills per launch around the call sites.)
+// Records from m on are padding (coordinates 0, a huge fourth word): no candidates.
+__device__ __forceinline__ void rescan_block_rec(double ax, double ay, double az, const double4 *rec, unsigned j0, unsigned m, double &bd,
+                                              double &bk, uint32_t &bj, double &dbest)
+{
+    asm volatile("" : "+v"(j0));
+    double dm = INFINITY, d2nd = INFINITY;
+    int um = 0;
+#pragma unroll
+    for (int u = 0; u < kBatchCB; ++u) {
+        const double4 v = rec[j0 + u];
+        const double d = (j0 + u < m) ? d2_exact(ax, ay, az, -0.5 * v.x, -0.5 * v.y, -0.5 * v.z) : INFINITY;
+        d2nd = __builtin_fmin(d2nd, __builtin_fmax(d, dm));
+        um = (d < dm) ? u : um;
+        dm = __builtin_fmin(dm, d);
+    }
+    if (!(dm < bd)) return;
+    if (d2nd > __builtin_fma(dm, 1.0 + 0x1p-48, 1e-300)) {
+        bd = dm;
+        const double key = key_of(dm);
+        const uint32_t j = j0 + (unsigned)um;
+        if (key < bk || (key == bk && j < bj)) {
+            bk = key;
+            bj = j;
+            dbest = dm;
+        }
+        return;
+    }
+#pragma unroll 1
+    for (int u = 0; u < kBatchCB; ++u) {
+        const double4 v = rec[j0 + u];
+        const double d = (j0 + u < m) ? d2_exact(ax, ay, az, -0.5 * v.x, -0.5 * v.y, -0.5 * v.z) : INFINITY;
+        if (d < bd) {
+            bd = d;
+            const double key = key_of(d);
+            const uint32_t j = j0 + (unsigned)u;
+            if (key < bk || (key == bk && j < bj)) {
+                bk = key;
+                bj = j;
+                dbest = d;
+            }
+        }
+    }
+}
+
+// bj: in, the previous iteration's matches (the seeds); out, this iteration's.  rec[j].w = |q_j|^2 + C.
+template <int PPL>
+__device__ __forceinline__ void scan_small_seeded(const double (&ax)[PPL], const double (&ay)[PPL], const double (&az)[PPL],
+                                                  const double4 *rec, unsigned m, unsigned m_pad, double qmax2, double C, uint32_t (&bj)[PPL])
+{
+    double bd[PPL], bk[PPL], off[PPL];
+    uint32_t bn[PPL], sblk[PPL], thr1[PPL], mh[PPL];   // thr1 = the threshold's high word + 1: an event is mh < thr1 (0: never)
+    bool ok[PPL];
+    const bool range_ok = qmax2 < 1e280 && C < 1e290;   // false also for NaN
+    const double qmax = sqrt(qmax2);
+#pragma unroll
+    for (int s = 0; s < PPL; ++s) {
+        const double pn = (ax[s] * ax[s] + ay[s] * ay[s]) + az[s] * az[s];
+        const double E = 0x1p-52 * (11.0 * sqrt(pn) * qmax + 5.0 * qmax2 + 8.0 * C);
+        ok[s] = range_ok && pn < 1e280 && C > 2.0 * pn + 4.0 * E;   // false also for NaN
+        off[s] = (C - pn * (1.0 - 0x1p-50)) + E;
+        // the seed, and its own block up front (seed_init, search_common.h)
+        bk[s] = INFINITY;
+        bn[s] = 0xFFFFFFFFu;
+        sblk[s] = 0xFFFFFFFFu;
+        bd[s] = INFINITY;
+        const uint32_t js = bj[s];
+        if (ok[s] && js < m) {
+            const double4 v = rec[js];
+            const double d = d2_exact(ax[s], ay[s], az[s], -0.5 * v.x, -0.5 * v.y, -0.5 * v.z);
+            if (d < INFINITY) {
+                bk[s] = key_of(d);
+                bn[s] = js;
+                double dbest = d, b0 = __builtin_fma(d, 1.0 + 0x1p-48, 1e-300);
+                rescan_block_rec(ax[s], ay[s], az[s], rec, (js / kBatchCB) * kBatchCB, m, b0, bk[s], bn[s], dbest);
+                sblk[s] = js / kBatchCB;
+                bd[s] = __builtin_fma(dbest, 1.0 + 0x1p-48, 1e-300);
+            }
+        }
+        const double thr = bd[s] < INFINITY ? __builtin_fma(bd[s], 1.0 + 0x1p-50, off[s]) * (1.0 + 0x1p-50) : INFINITY;
+        thr1[s] = !ok[s] ? 0u : (thr < INFINITY ? (uint32_t)__double2hiint(thr) + 1u : 0x7FF00000u);
+        mh[s] = thr1[s];
+    }
+    for (unsigned j0 = 0; j0 < m_pad; j0 += kBatchCB) {
+#pragma unroll
+        for (unsigned u = 0; u < (unsigned)kBatchCB; u += 2) {
+            const double4 v0 = rec[j0 + u], v1 = rec[j0 + u + 1];
+#pragma unroll
+            for (int s = 0; s < PPL; ++s) {
+                const double f0 = __builtin_fma(az[s], v0.z, __builtin_fma(ay[s], v0.y, __builtin_fma(ax[s], v0.x, v0.w)));
+                const double f1 = __builtin_fma(az[s], v1.z, __builtin_fma(ay[s], v1.y, __builtin_fma(ax[s], v1.x, v1.w)));
+                mh[s] = umin3(mh[s], (uint32_t)__double2hiint(f0), (uint32_t)__double2hiint(f1));
+            }
+        }
+        const unsigned blk = j0 / kBatchCB;
+        bool ev = false;
+#pragma unroll
+        for (int s = 0; s < PPL; ++s) {
+            if (blk == sblk[s]) mh[s] = thr1[s];
+            ev |= (mh[s] < thr1[s]);
+        }
+        if (ev) {
+#pragma unroll
+            for (int s = 0; s < PPL; ++s) {
+                if (mh[s] < thr1[s]) {
+                    double dbest;
+                    rescan_block_rec(ax[s], ay[s], az[s], rec, j0, m, bd[s], bk[s], bn[s], dbest);
+                    const double thr = bd[s] < INFINITY ? __builtin_fma(bd[s], 1.0 + 0x1p-50, off[s]) * (1.0 + 0x1p-50) : INFINITY;
+                    thr1[s] = thr < INFINITY ? (uint32_t)__double2hiint(thr) + 1u : 0x7FF00000u;
+                    mh[s] = thr1[s];
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < PPL; ++s) bj[s] = ok[s] ? bn[s] : exact_scan_small_rec(ax[s], ay[s], az[s], rec, m);
+}
+
 // ------------------------------------------------------------------------------------------------
 // multi-registration mode: one workgroup = one whole registration, every iteration on-chip
 // ------------------------------------------------------------------------------------------------
@@ -998,7 +1135,8 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(PPL == 4 ? 
                                                         double *__restrict__ rec_out, uint32_t *__restrict__ idx_out)
 {
     extern __shared__ double lds[];
-    constexpr bool EXP = MODE == kExpanded;   // targets as {-2q, |q|^2} records (4 doubles) instead of SoA (3 doubles)
+    constexpr bool EXP = MODE == kExpanded || MODE == kSeeded;   // targets as {-2q, |q|^2} records (4 doubles) instead of SoA (3 doubles)
+    constexpr bool SEEDED = MODE == kSeeded;                     // from the second iteration on: scan_small_seeded
     double *sx = lds, *sy = lds + m_pad, *sz = lds + 2 * (size_t)m_pad;
     double4 *trec = (double4 *)lds;
     double *red = lds + (EXP ? 4 : 3) * (size_t)m_pad;  // 4*12: scratch of block_sum
@@ -1130,7 +1268,41 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(PPL == 4 ? 
             ay[s] = py[s] - c1;
             az[s] = pz[s] - c2;
         }
-        if constexpr (EXP)
+        if constexpr (SEEDED) {
+            if (it == 1) {
+                // C = a power of two >= 4 max(|a|^2 over the rows, |q|^2 over the targets), added to every record's fourth word
+                // (the first iteration, which read the plain |q|^2, is over; nothing else reads that word)
+                double pm = 0.0;
+#pragma unroll
+                for (int s = 0; s < PPL; ++s) {
+                    const double pn = (ax[s] * ax[s] + ay[s] * ay[s]) + az[s] * az[s];
+                    pm = (s * kWG + tid < n && (pn > pm || pn != pn)) ? pn : pm;   // a NaN sticks
+                }
+#pragma unroll
+                for (int o = 32; o >= 1; o >>= 1) {
+                    const double other = __shfl_xor(pm, o, 64);
+                    pm = (other > pm || other != other) ? other : pm;
+                }
+                if ((tid & 63) == 0) red[tid >> 6] = pm;
+                __syncthreads();
+                if (tid == 0) {
+                    double v = bc[3];
+                    for (int w = 0; w < kWG / 64; ++w) v = (red[w] > v || red[w] != red[w]) ? red[w] : v;
+                    bc[19] = (v > 0.0 && v < 1e280) ? __builtin_amdgcn_ldexp(1.0, __builtin_amdgcn_frexp_exp(v) + 2) : INFINITY;
+                }
+                __syncthreads();
+                const double C = bc[19];
+                if (C < INFINITY)
+                    for (unsigned j = tid; j < m; j += kWG) trec[j].w += C;
+                __syncthreads();
+            }
+            if (it == 0) scan_small_expanded<PPL>(ax, ay, az, trec, m, m_pad, bc[3], bj);
+            else if (bc[19] < INFINITY) scan_small_seeded<PPL>(ax, ay, az, trec, m, m_pad, bc[3], bc[19], bj);
+            else {   // no usable offset (a degenerate or out-of-range registration): every row exactly
+#pragma unroll
+                for (int s = 0; s < PPL; ++s) bj[s] = exact_scan_small_rec(ax[s], ay[s], az[s], trec, m);
+            }
+        } else if constexpr (EXP)
             scan_small_expanded<PPL>(ax, ay, az, trec, m, m_pad, bc[3], bj);
         else
             scan_small<PPL, MODE>(ax, ay, az, sx, sy, sz, m, m_pad, bj);
@@ -1489,7 +1661,7 @@ template <int PPL, int MODE, bool STRICT>
 static hipError_t batch_launch(hipStream_t s, const double *P_in, const double *Q_in, size_t batch, size_t n, size_t m, unsigned iters,
                                double *P_out, double *rec_out, uint32_t *idx_out)
 {
-    size_t lds = ((MODE == kExpanded ? 4 : 3) * ((m + 31) / 32 * 32) + 48 + 48) * sizeof(double);
+    size_t lds = (((MODE == kExpanded || MODE == kSeeded) ? 4 : 3) * ((m + 31) / 32 * 32) + 48 + 48) * sizeof(double);
     if (STRICT) lds += 3 * ((n + 1) & ~(size_t)1) * sizeof(double) + ((n + 1) & ~(size_t)1) * sizeof(uint32_t);
     auto kern = batch_icp_kernel<PPL, MODE, STRICT>;
     if (lds > 48 * 1024) {
@@ -1509,7 +1681,8 @@ hipError_t batch_icp(hipStream_t s, int variant, bool strict, const double *P_in
         return batch_launch<8, kExact, true>(s, P_in, Q_in, batch, n, m, iters, P_out, rec_out, idx_out);
     }
 #define ICPK_BATCH(PPL_) \
-    return variant == kExpanded ? batch_launch<PPL_, kExpanded, false>(s, P_in, Q_in, batch, n, m, iters, P_out, rec_out, idx_out) \
+    return variant == kSeeded   ? batch_launch<PPL_, kSeeded, false>(s, P_in, Q_in, batch, n, m, iters, P_out, rec_out, idx_out) \
+           : variant == kExpanded ? batch_launch<PPL_, kExpanded, false>(s, P_in, Q_in, batch, n, m, iters, P_out, rec_out, idx_out) \
            : variant == kFma    ? batch_launch<PPL_, kFma, false>(s, P_in, Q_in, batch, n, m, iters, P_out, rec_out, idx_out) \
                                 : batch_launch<PPL_, kExact, false>(s, P_in, Q_in, batch, n, m, iters, P_out, rec_out, idx_out)
     if (n <= 1024) ICPK_BATCH(4);

@@ -143,6 +143,35 @@ def test_batch_expanded_form_is_only_a_filter():
         assert np.array_equal(want["P_out"], got["P_out"], equal_nan=True), k
 
 
+@pytest.mark.parametrize("seeded", ["1", "0"])
+def test_batch_filters_on_ragged_target_counts(monkeypatch, seeded):
+    """Target counts that are no multiple of the scan block (padding records sit inside the last block, and a block
+    re-scan must not take them for points at the origin), fewer targets than one block, both source size classes, clouds
+    around the origin: the default search (seeded from the second iteration on; ICP_AMD_BATCH_SEEDED=0 = the expanded form
+    on every iteration) must give the EXACT variant's results bit for bit."""
+    monkeypatch.setenv("ICP_AMD_BATCH_SEEDED", seeded)
+    rng = np.random.RandomState(31)
+    for n, m in ((1445, 95), (2048, 6), (121, 17), (1613, 3022), (1447, 1), (300, 7), (1024, 4095), (9, 2049)):
+        for kind in range(3):
+            if kind == 0:      # uniform around the origin
+                Q, P = rng.uniform(-1, 1, (3, m, 3)), rng.uniform(-1, 1, (3, n, 3))
+            elif kind == 1:    # small lattice with half-step offsets: exact ties, many duplicates
+                Q = rng.randint(-5, 6, (3, m, 3)).astype(np.float64)
+                P = rng.randint(-5, 6, (3, n, 3)).astype(np.float64) + rng.choice([0.0, 0.5], (3, n, 3))
+            else:              # far from the origin at a small scale
+                Q, P = rng.uniform(-1, 1, (3, m, 3)) * 1e-3 + 7.0, rng.uniform(-1, 1, (3, n, 3)) * 1e-3 + 7.0
+            b = icp_amd.Batch(3, n, m)
+            b.upload(P, Q)
+            b.run(4, search="exact")
+            want = b.download()
+            b.run(4, search="auto")
+            got = b.download()
+            b.close()
+            assert got["idx"].max() < m
+            assert np.array_equal(want["idx"], got["idx"]), (n, m, kind)
+            assert np.array_equal(want["P_out"], got["P_out"], equal_nan=True), (n, m, kind)
+
+
 def test_cli_batch_argument(tmp_path):
     import os
     import subprocess
