@@ -83,6 +83,33 @@ def test_seeded_form_error_bound_and_threshold_hold_in_exact_arithmetic():
     print("largest |f - F| / E observed: %.3f" % worst)
 
 
+def test_expanded_form_error_bound_holds_in_exact_arithmetic():
+    """The first iteration's filter (scan_small_expanded): f = fma chain on {-2q, |q|^2}, F = |a - q|^2 - |a|^2,
+    |f - F| <= E = 2^-52 (11 |a| qmax + 5 qmax^2)."""
+    rng = np.random.RandomState(6)
+    worst = 0.0
+    for scale in (1.0, 1e-4, 1e7, 1e-90, 1e90):
+        for a_ratio, q_ratio in ((1.0, 1.0), (1.0, 1e-3), (1e-3, 1.0), (30.0, 1.0), (1.0, 30.0)):
+            A = rng.uniform(-1, 1, (8, 3)) * scale * a_ratio
+            Q = rng.uniform(-1, 1, (40, 3)) * scale * q_ratio
+            Q[0] = A[0]
+            qn = [norm2(*q) for q in Q]
+            qmax2 = max(qn)
+            qmax = math.sqrt(qmax2)
+            for a in A:
+                pn = norm2(*a)
+                E = 2.0 ** -52 * (11.0 * math.sqrt(pn) * qmax + 5.0 * qmax2)
+                pn_exact = sum(Fr(v) * Fr(v) for v in a)
+                for q, w in zip(Q, qn):
+                    f = fma(a[2], -2.0 * q[2], fma(a[1], -2.0 * q[1], fma(a[0], -2.0 * q[0], w)))
+                    F = sum((Fr(a[k]) - Fr(q[k])) ** 2 for k in range(3)) - pn_exact
+                    err = abs(Fr(f) - F)
+                    assert err <= Fr(E), (scale, a_ratio, q_ratio, float(err), E)
+                    worst = max(worst, float(err / Fr(E)))
+    assert 0.0 < worst < 1.0
+    print("expanded form: largest |f - F| / E observed: %.3f" % worst)
+
+
 def test_offset_is_a_power_of_two_above_four_times_the_range():
     for v in (1e-300, 3.0, 4.0, 0.75, 1.0, 123456.789, 1e279):
         C = offset_C(v)
