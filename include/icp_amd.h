@@ -192,7 +192,10 @@ int icp_amd_grid_stats(icp_amd_engine *e, unsigned *grid_launches, unsigned *bru
 typedef struct icp_amd_batch icp_amd_batch;
 int icp_amd_batch_create(icp_amd_batch **out, int device, size_t batch, size_t n, size_t m);
 int icp_amd_batch_upload(icp_amd_batch *b, const double *P /* batch*n*3 */, const double *Q /* batch*m*3 */);
-/* Runs `iters` iterations from the uploaded clouds (every call starts again from them). elapsed_ms optional. */
+/* Runs `iters` iterations from the uploaded clouds (every call starts again from them). elapsed_ms optional.
+ * `search`: ICP_AMD_SEARCH_EXACT / _FMA = the all-fp64 difference forms; anything else = the default (a filter on
+ * {-2q, |q|^2} records, seeded by the previous iteration's match from the second iteration on; every candidate
+ * re-evaluated in the oracle's arithmetic).  All give the same bits. */
 int icp_amd_batch_run(icp_amd_batch *b, unsigned iters, int search, double *elapsed_ms);
 /* Any pointer may be NULL. R (batch*9), t (batch*3), cov (batch*9), rms (batch): last iteration's. idx: batch*n. */
 int icp_amd_batch_download(icp_amd_batch *b, double *P_out, double *R, double *t, double *cov, int32_t *idx, double *rms);
