@@ -38,6 +38,10 @@ while time.time() < t_end:
         Q = rng.uniform(-1, 1, (B, m, 3))
         c, s_ = np.cos(0.1), np.sin(0.1)
         P = Q[:, rng.randint(0, m, n)] @ np.array([[c, -s_, 0], [s_, c, 0], [0, 0, 1.0]]).T + 1e-3 * rng.standard_normal((B, n, 3))
+    if rng.randint(12) == 0:   # a few non-finite coordinates: every path must agree on what they do to the registration
+        for _ in range(int(rng.randint(1, 4))):
+            X = P if rng.randint(2) else Q
+            X[rng.randint(B), rng.randint(X.shape[1]), rng.randint(3)] = rng.choice([np.nan, np.inf, -np.inf])
     b = icp_amd.Batch(B, n, m)
     b.upload(P, Q)
     b.run(iters, search="exact"); want = b.download()
