@@ -46,6 +46,11 @@ while time.time() < t_end:
         P = rng.uniform(-1, 1, (n, 3)) * np.array([1.0, 1.0, rng.choice([0.0, 1.0])])
     Pc = orc.mean0(P)
     Qz = Q - orc.mean0(Q)
+    if rng.randint(12) == 0:   # a few non-finite coordinates in single rows (behind the centring, so that the other rows
+        P, Q = P.copy(), Q.copy()   # stay finite): every variant must do with them what the oracle does
+        for _ in range(int(rng.randint(1, 4))):
+            X = P if rng.randint(2) else Qz
+            X[rng.randint(len(X)), rng.randint(3)] = rng.choice([np.nan, np.inf, -np.inf])
     want = orc.correspondences(P - Pc, Qz, nthreads=8)
     # half the cases run the brute-force launches truly un-seeded (the cooperative exact path of the matrix filter), the
     # other half seeded from the grid's answer like the engine's first iteration
