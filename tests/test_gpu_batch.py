@@ -172,6 +172,24 @@ def test_batch_filters_on_ragged_target_counts(monkeypatch, seeded):
             assert np.array_equal(want["P_out"], got["P_out"], equal_nan=True), (n, m, kind)
 
 
+def test_batch_edge_shapes_and_iteration_counts():
+    """One point, one target, the kernel's largest clouds, and 0 to 3 iterations (0: nothing runs; 1: only the first
+    iteration's form; 2: the first seeded one): the default search against the EXACT variant, every output, bit for bit."""
+    rng = np.random.RandomState(3)
+    for n, m in ((1000, 1000), (1, 1), (2048, 4096), (5, 4096), (2048, 1)):
+        P, Q = rng.uniform(-1, 1, (3, n, 3)), rng.uniform(-1, 1, (3, m, 3))
+        b = icp_amd.Batch(3, n, m)
+        b.upload(P, Q)
+        for iters in (0, 1, 2, 3):
+            b.run(iters, search="exact")
+            want = b.download()
+            b.run(iters, search="auto")
+            got = b.download()
+            for k in ("idx", "P_out", "R", "t", "cov", "rms"):
+                assert np.array_equal(want[k], got[k], equal_nan=True), (n, m, iters, k)
+        b.close()
+
+
 def test_cli_batch_argument(tmp_path):
     import os
     import subprocess
