@@ -266,7 +266,7 @@ def measure_batch(args, rank, world, local_rank, steps, warmup, with_cpu):
     ach = FLOPS_PER_PAIR * float(hi - lo) * n * n * args.batch_iters / (kms / steps * 1e-3)
     issue_frac = None
     if os.environ.get("ICP_AMD_SEARCH", "") not in ("exact", "fma"):   # the default forms; the difference forms have other counts
-        seeded = os.environ.get("ICP_AMD_BATCH_SEEDED", "1") != "0"
+        seeded = os.environ.get("ICP_AMD_BATCH_SEEDED", "1" if n >= 384 else "0") != "0"   # the library's own default
         instr = float(hi - lo) * n * n * (7.0 + (3.5 if seeded else 7.0) * (args.batch_iters - 1))
         issue_frac = instr / (kms / steps * 1e-3) / (CUS * 4 * 16 * CLOCK_HZ)
     cpu = None

@@ -1384,9 +1384,10 @@ extern "C" int icp_amd_batch_run(icp_amd_batch *b, unsigned iters, int search_va
     if (!b->uploaded) return fail(ICP_AMD_ESTATE, "icp_amd_batch_run: upload the clouds first");
     HIPCHK(set_device(b->device));
     // EXACT / FMA: the difference form on SoA targets; anything else (AUTO, F32, GRID): the expanded form on records
-    // default: the expanded form, seeded from the second iteration on (ICP_AMD_DEBUG batch_seeded=0: the expanded form throughout)
+    // default: the expanded form, from 384 targets on seeded from the second iteration on (below, the seed blocks cost what the
+    // shorter fast path saves: 256 x 256 points 10.2 ms unseeded against 11.1; ICP_AMD_DEBUG batch_seeded=0 / 1 decides for every size)
     int variant = search_variant == ICP_AMD_SEARCH_EXACT ? kExact : search_variant == ICP_AMD_SEARCH_FMA ? kFma
-                  : knob_int("batch_seeded", 1) ? kSeeded : kExpanded;
+                  : knob_int("batch_seeded", b->m >= 384 ? 1 : 0) ? kSeeded : kExpanded;
     const char *sv = search_variant == ICP_AMD_SEARCH_AUTO ? getenv("ICP_AMD_SEARCH") : nullptr;   // an explicit variant wins
     if (sv && !strcmp(sv, "fma")) variant = kFma;
     if (sv && !strcmp(sv, "exact")) variant = kExact;

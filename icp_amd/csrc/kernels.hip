@@ -1130,7 +1130,7 @@ __device__ __forceinline__ void scan_small_seeded(const double (&ax)[PPL], const
 // and as the engine's strict order does (strict_centroid_kernel / strict_cov_kernel): Qc, Pc and cov carry the reference's
 // bits.  The running cloud and the indices are staged in LDS for that (3 n doubles + n words behind the solve record).
 template <int PPL, int MODE, bool STRICT = false>
-__global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(PPL == 4 ? 3 : 2))) void batch_icp_kernel(const double *__restrict__ P_in, const double *__restrict__ Q_in, unsigned n,
+__global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(PPL <= 4 ? 3 : 2))) void batch_icp_kernel(const double *__restrict__ P_in, const double *__restrict__ Q_in, unsigned n,
                                                         unsigned m, unsigned m_pad, unsigned iters, double *__restrict__ P_out,
                                                         double *__restrict__ rec_out, uint32_t *__restrict__ idx_out)
 {
@@ -1141,7 +1141,9 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(PPL == 4 ? 
     double4 *trec = (double4 *)lds;
     double *red = lds + (EXP ? 4 : 3) * (size_t)m_pad;  // 4*12: scratch of block_sum
     double *bc = red + 48;                  // [0..2] Pc, [4..15] cov sums, [16..18] Qc, [20..47] solve record
-    constexpr int NCH = PPL / 4;            // 1024-row chunks covered by the PPL*256 slots
+    constexpr int NCH = (PPL + 3) / 4;      // 1024-row chunks covered by the PPL*256 slots
+    constexpr int KPC = PPL < 4 ? PPL : 4;  // slots per chunk: clouds of up to 256 / 512 rows keep 1 / 2 rows per lane -- the rows a
+                                            // 4-slot lane would add to them do not exist, so the chunk sum has the same terms in the same order
     const unsigned tid = threadIdx.x;
     static_assert(!STRICT || MODE == kExact, "strict order reads the targets from the SoA layout");
     const unsigned np = (n + 1u) & ~1u;     // STRICT: rows of the staged cloud (sp[k * np + i]), then the staged indices
@@ -1244,7 +1246,7 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(PPL == 4 ? 
         for (int c = 0; c < NCH; ++c) {
             double acc[3] = {0.0, 0.0, 0.0};
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
+            for (int k = 0; k < KPC; ++k) {
                 const int s = c * 4 + k;
                 if (s * kWG + tid < n) {
                     acc[0] += px[s];
@@ -1315,7 +1317,7 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(PPL == 4 ? 
 #pragma unroll
             for (int k = 0; k < kCovW; ++k) acc[k] = 0.0;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
+            for (int k = 0; k < KPC; ++k) {
                 const int s = c * 4 + k;
                 const uint32_t j = bj[s];
                 if (s * kWG + tid < n && j < m) {
@@ -1685,6 +1687,8 @@ hipError_t batch_icp(hipStream_t s, int variant, bool strict, const double *P_in
            : variant == kExpanded ? batch_launch<PPL_, kExpanded, false>(s, P_in, Q_in, batch, n, m, iters, P_out, rec_out, idx_out) \
            : variant == kFma    ? batch_launch<PPL_, kFma, false>(s, P_in, Q_in, batch, n, m, iters, P_out, rec_out, idx_out) \
                                 : batch_launch<PPL_, kExact, false>(s, P_in, Q_in, batch, n, m, iters, P_out, rec_out, idx_out)
+    if (n <= 256) ICPK_BATCH(1);
+    if (n <= 512) ICPK_BATCH(2);
     if (n <= 1024) ICPK_BATCH(4);
     ICPK_BATCH(8);
 #undef ICPK_BATCH

@@ -7,7 +7,7 @@ import numpy as np
 import icp_amd
 from icp_amd import synth
 
-print("seeded form:", os.environ.get("ICP_AMD_BATCH_SEEDED", "1") != "0", flush=True)
+print("ICP_AMD_BATCH_SEEDED =", os.environ.get("ICP_AMD_BATCH_SEEDED", "unset (seeded from 384 targets on)"), flush=True)
 for B, n, m in ((16384, 256, 256), (8192, 512, 512), (4096, 1000, 1000), (4096, 1024, 2048), (2048, 2048, 2048), (1024, 2048, 4096), (256, 1000, 1000)):
     P, Q = synth.make_batch(32, max(n, m), seed=synth.SEED_Q)
     P, Q = np.tile(P[:, :n], (B // 32, 1, 1)), np.tile(Q[:, :m], (B // 32, 1, 1))
