@@ -1130,7 +1130,7 @@ __device__ __forceinline__ void scan_small_seeded(const double (&ax)[PPL], const
 // and as the engine's strict order does (strict_centroid_kernel / strict_cov_kernel): Qc, Pc and cov carry the reference's
 // bits.  The running cloud and the indices are staged in LDS for that (3 n doubles + n words behind the solve record).
 template <int PPL, int MODE, bool STRICT = false>
-__global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(PPL <= 4 ? 3 : 2))) void batch_icp_kernel(const double *__restrict__ P_in, const double *__restrict__ Q_in, unsigned n,
+__global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(PPL <= 2 ? 4 : PPL == 4 ? 3 : 2))) void batch_icp_kernel(const double *__restrict__ P_in, const double *__restrict__ Q_in, unsigned n,
                                                         unsigned m, unsigned m_pad, unsigned iters, double *__restrict__ P_out,
                                                         double *__restrict__ rec_out, uint32_t *__restrict__ idx_out)
 {
